@@ -1,0 +1,145 @@
+/*
+ * rsparse_hip.h -- C ABI of librsparse_hip.so: an MI355X (gfx950) implementation of the
+ * numeric solve path of RLado/rsparse (sparse triangular solves, numeric Cholesky, and the
+ * cholsol / lusol drivers).  Symbolic analysis runs on the host CPU, numeric work on the GPU.
+ *
+ * The reference has no FFI; its boundary is its public Rust functions.  Every entry point
+ * below names the reference function (file:line in rsparse v1.2.1) it replaces.  All
+ * pointers are HOST pointers unless the name says `_dev`.  Index types are those of the
+ * reference on x86-64: `isize` -> int64_t, `usize` -> uint64_t.
+ *
+ * Rules: nothing throws or aborts across this boundary; every function returns an
+ * rsp_status.  RSP_NOT_POSITIVE_DEFINITE / RSP_NO_PIVOT are the reference's two
+ * `Error` variants (src/lib.rs:189-194); negative codes have no Rust counterpart
+ * (bad input, no usable GPU) and are reported, never papered over with a CPU path.
+ */
+#ifndef RSPARSE_HIP_H
+#define RSPARSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Borrowed view of rsparse::data::Sprs<f64> (src/data.rs:194-208): CSC, nnz = p[n] (never nzmax),
+ * row indices inside a column in any order unless stated. */
+typedef struct {
+    int64_t nzmax, m, n;
+    const int64_t *p;  /* n+1 column pointers (Vec<isize>) */
+    const uint64_t *i; /* row indices           (Vec<usize>) */
+    const double *x;   /* values                (Vec<f64>)   */
+} rsp_csc_f64;
+
+enum rsp_status {
+    RSP_OK = 0,
+    RSP_NOT_POSITIVE_DEFINITE = 1, /* Error::NotPositiveDefinite, src/lib.rs:191 */
+    RSP_NO_PIVOT = 2,              /* Error::NoPivot,             src/lib.rs:193 */
+    RSP_BAD_INPUT = -1,            /* the reference would panic on a bounds check */
+    RSP_DEVICE_ERROR = -2          /* HIP error / no gfx950 device visible */
+};
+
+/* which triangular system a handle solves; names follow the reference functions */
+enum rsp_tri_kind {
+    RSP_LSOLVE = 0,  /* L x = b,  L lower, diagonal FIRST in each column (src/lib.rs:464) */
+    RSP_LTSOLVE = 1, /* L' x = b, same storage                           (src/lib.rs:505) */
+    RSP_USOLVE = 2,  /* U x = b,  U upper, diagonal LAST in each column  (src/lib.rs:1230) */
+    RSP_UTSOLVE = 3  /* U' x = b, same storage                           (src/lib.rs:1271) */
+};
+
+/* layout of a device-resident block of right-hand sides */
+enum rsp_layout {
+    RSP_COL_MAJOR = 0, /* X[i + r*ld]: each right-hand side contiguous (a Rust `&mut [f64]` per column) */
+    RSP_ROW_MAJOR = 1  /* X[i*ld + r]: the nrhs values of one unknown contiguous (the kernels' native layout) */
+};
+
+const char *rsp_status_string(int status);
+int rsp_device_count(void);     /* number of visible HIP devices (0 if none) */
+int rsp_set_device(int device); /* device used by the calling thread's later calls */
+
+/* ---- one-shot triangular solves, x overwritten in place -------------------------------------
+ * rsparse::lsolve / ltsolve / usolve / utsolve (src/lib.rs:464-471, 505-512, 1230-1237, 1271-1278).
+ * Same conventions: lsolve/ltsolve need the diagonal first in every column, usolve/utsolve last. */
+int rsp_lsolve_f64(const rsp_csc_f64 *L, double *x);
+int rsp_ltsolve_f64(const rsp_csc_f64 *L, double *x);
+int rsp_usolve_f64(const rsp_csc_f64 *U, double *x);
+int rsp_utsolve_f64(const rsp_csc_f64 *U, double *x);
+
+/* ---- analyse-once / solve-many triangular handle (no reference counterpart: the reference
+ *      re-walks the matrix on every call; this caches the device copy and the level schedule) ---- */
+typedef struct rsp_tri rsp_tri;
+int rsp_tri_analyze(const rsp_csc_f64 *T, int kind, rsp_tri **out);
+/* X = host, column-major n x nrhs with leading dimension ldx >= n; overwritten with the solutions */
+int rsp_tri_solve_f64(rsp_tri *h, double *X, int64_t ldx, int64_t nrhs);
+/* dX = device pointer; layout/ld as rsp_layout; runs on `stream` (a hipStream_t, NULL = default)
+ * and returns without synchronising */
+int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_t nrhs, void *stream);
+/* info[0..7] = n, nnz, levels, tasks, kernel launches per sweep, device bytes of the factor copy,
+ *              algorithmic bytes for one sweep of 1 rhs, longest task (rows) */
+int rsp_tri_info(const rsp_tri *h, int64_t *info);
+/* integer schedule, for bit-exact comparison with the host oracle: level_of_row[n] */
+int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row);
+void rsp_tri_free(rsp_tri *h);
+
+/* ---- symbolic analysis (host CPU) -------------------------------------------------------------
+ * rsparse::schol (src/lib.rs:968-986) and the LU branch of rsparse::sqr (src/lib.rs:1114-1119,1134-1137).
+ * rsp_symb mirrors rsparse::data::Symb (src/data.rs:1022-1038). */
+typedef struct rsp_symb rsp_symb;
+int rsp_schol(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
+int rsp_sqr_lu(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
+/* build a Symb from caller-held vectors (pinv/q may be NULL = None) -- for chol(a, &mut s) with any s */
+int rsp_symb_from_parts(int64_t n, const int64_t *pinv, const int64_t *q, const int64_t *parent, const int64_t *cp,
+                        rsp_symb **S);
+int64_t rsp_symb_n(const rsp_symb *S);
+const int64_t *rsp_symb_pinv(const rsp_symb *S);   /* n entries, or NULL for None */
+const int64_t *rsp_symb_q(const rsp_symb *S);      /* n+1 entries as amd returns them, or NULL for None */
+const int64_t *rsp_symb_parent(const rsp_symb *S); /* n entries (schol only) */
+const int64_t *rsp_symb_cp(const rsp_symb *S);     /* n+1 entries (schol only) */
+int64_t rsp_symb_lnz(const rsp_symb *S);
+int64_t rsp_symb_unz(const rsp_symb *S);
+void rsp_symb_free(rsp_symb *S);
+/* the ordering alone: rsparse's private amd (src/lib.rs:1292-1752). Returns RSP_OK and *has_perm = 0
+ * for the natural ordering (order < 0), else writes n+1 entries to P. */
+int rsp_amd(const rsp_csc_f64 *A, int8_t order, int64_t *P, int *has_perm);
+
+/* ---- numeric Cholesky -------------------------------------------------------------------------
+ * rsparse::chol (src/lib.rs:278-337): L has L.p == S.cp, diagonal first then rows ascending.
+ * Caller allocates Lp[n+1], Li[cp[n]], Lx[cp[n]] (the fields of Nmrc.l). Pattern on host, values on GPU. */
+int rsp_chol_f64(const rsp_csc_f64 *A, const rsp_symb *S, int64_t *Lp, uint64_t *Li, double *Lx);
+
+/* factor kept on the device for repeated solves (no reference counterpart; cholsol refactors each call) */
+typedef struct rsp_chol rsp_chol;
+int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F);
+/* B host column-major n x nrhs: B <- A^-1 B through P, lsolve, ltsolve, P' (src/lib.rs:383-386) */
+int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs);
+/* device-resident variant; `permute` = 0 skips P/P' (solves L L' y = b in the permuted ordering) */
+int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int64_t nrhs, int permute, void *stream);
+int64_t rsp_chol_lnz(const rsp_chol *F);
+int rsp_chol_get_factor(const rsp_chol *F, int64_t *Lp, uint64_t *Li, double *Lx);
+/* info[0..9] = n, lnz, supernodes, supernodal levels, flops (sum of squared column counts), algorithmic bytes,
+ *              lsolve levels, lsolve launches, ltsolve levels, ltsolve launches */
+int rsp_chol_info(const rsp_chol *F, int64_t *info);
+/* last numeric-factorisation time measured with HIP events on the library's stream, milliseconds */
+double rsp_chol_factor_ms(const rsp_chol *F);
+void rsp_chol_free(rsp_chol *F);
+
+/* rsparse::cholsol (src/lib.rs:377-389): b overwritten with A\b */
+int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
+
+/* ---- LU ---------------------------------------------------------------------------------------
+ * rsparse::lu (src/lib.rs:519-622) runs on the host (pivot sequence must be bit-exact with the
+ * reference); rsparse::lusol (src/lib.rs:672-683) then solves with L and U on the GPU. */
+typedef struct rsp_lu rsp_lu;
+int rsp_lu_f64(const rsp_csc_f64 *A, const rsp_symb *S, double tol, rsp_lu **N);
+int rsp_lu_L(const rsp_lu *N, rsp_csc_f64 *L); /* borrowed views, valid until rsp_lu_free */
+int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U);
+const int64_t *rsp_lu_pinv(const rsp_lu *N);   /* n entries */
+/* b <- A^-1 b for nrhs host column-major right-hand sides (ipvec, lsolve, usolve, ipvec: src/lib.rs:678-681) */
+int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs);
+void rsp_lu_free(rsp_lu *N);
+int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSPARSE_HIP_H */

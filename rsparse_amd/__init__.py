@@ -1,0 +1,33 @@
+"""rsparse_amd -- host-side mirror of rsparse's numeric solve path over librsparse_hip.so (MI355X / gfx950).
+
+Same function names, argument meaning and error behaviour as the reference's public API for this path
+(/root/reference/src/lib.rs): lsolve, ltsolve, usolve, utsolve, schol, chol, cholsol, sqr, lu, lusol on
+`Sprs` matrices.  Symbolic analysis runs on the host inside the library, numeric work on the GPU.
+There is no CPU fallback: importing fails loudly if the HIP library has not been built
+(`make -C rsparse_amd/csrc`, or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+from .api import (  # noqa: F401
+    CholHandle,
+    DeviceError,
+    Error,
+    LuHandle,
+    NoPivot,
+    Nmrc,
+    NotPositiveDefinite,
+    Sprs,
+    Symb,
+    TriHandle,
+    amd,
+    chol,
+    cholsol,
+    device_count,
+    lib,
+    lsolve,
+    ltsolve,
+    lu,
+    lusol,
+    schol,
+    sqr,
+    usolve,
+    utsolve,
+)

@@ -1,0 +1,397 @@
+"""ctypes binding of include/rsparse_hip.h, shaped like rsparse's public Rust API (src/lib.rs, src/data.rs)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librsparse_hip.so")
+
+RSP_OK, RSP_NOT_POSITIVE_DEFINITE, RSP_NO_PIVOT, RSP_BAD_INPUT, RSP_DEVICE_ERROR = 0, 1, 2, -1, -2
+LSOLVE, LTSOLVE, USOLVE, UTSOLVE = 0, 1, 2, 3
+COL_MAJOR, ROW_MAJOR = 0, 1
+
+
+class Error(Exception):
+    """rsparse::Error (src/lib.rs:189-194)."""
+
+
+class NotPositiveDefinite(Error):
+    pass
+
+
+class NoPivot(Error):
+    pass
+
+
+class DeviceError(RuntimeError):
+    """No counterpart in the reference: bad input or HIP failure (negative status)."""
+
+
+class _Csc(C.Structure):
+    _fields_ = [("nzmax", C.c_int64), ("m", C.c_int64), ("n", C.c_int64), ("p", C.c_void_p), ("i", C.c_void_p),
+                ("x", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library. Raises if it was not built: the product has no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(f"{_LIB_PATH} is missing: build it with `make -C rsparse_amd/csrc` (hipcc, gfx950)")
+        L = C.CDLL(_LIB_PATH)
+        vp, i64, dbl, cint = C.c_void_p, C.c_int64, C.c_double, C.c_int
+        csc = C.POINTER(_Csc)
+        sig = {
+            "rsp_status_string": (C.c_char_p, [cint]),
+            "rsp_device_count": (cint, []),
+            "rsp_set_device": (cint, [cint]),
+            "rsp_lsolve_f64": (cint, [csc, vp]),
+            "rsp_ltsolve_f64": (cint, [csc, vp]),
+            "rsp_usolve_f64": (cint, [csc, vp]),
+            "rsp_utsolve_f64": (cint, [csc, vp]),
+            "rsp_tri_analyze": (cint, [csc, cint, C.POINTER(vp)]),
+            "rsp_tri_solve_f64": (cint, [vp, vp, i64, i64]),
+            "rsp_tri_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, vp]),
+            "rsp_tri_info": (cint, [vp, vp]),
+            "rsp_tri_levels": (cint, [vp, vp]),
+            "rsp_tri_free": (None, [vp]),
+            "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
+            "rsp_sqr_lu": (cint, [csc, C.c_int8, C.POINTER(vp)]),
+            "rsp_symb_from_parts": (cint, [i64, vp, vp, vp, vp, C.POINTER(vp)]),
+            "rsp_symb_n": (i64, [vp]),
+            "rsp_symb_pinv": (vp, [vp]),
+            "rsp_symb_q": (vp, [vp]),
+            "rsp_symb_parent": (vp, [vp]),
+            "rsp_symb_cp": (vp, [vp]),
+            "rsp_symb_lnz": (i64, [vp]),
+            "rsp_symb_unz": (i64, [vp]),
+            "rsp_symb_free": (None, [vp]),
+            "rsp_amd": (cint, [csc, C.c_int8, vp, C.POINTER(cint)]),
+            "rsp_chol_f64": (cint, [csc, vp, vp, vp, vp]),
+            "rsp_chol_factor_f64": (cint, [csc, vp, C.POINTER(vp)]),
+            "rsp_chol_solve_f64": (cint, [vp, vp, i64, i64]),
+            "rsp_chol_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, cint, vp]),
+            "rsp_chol_lnz": (i64, [vp]),
+            "rsp_chol_get_factor": (cint, [vp, vp, vp, vp]),
+            "rsp_chol_info": (cint, [vp, vp]),
+            "rsp_chol_factor_ms": (dbl, [vp]),
+            "rsp_chol_free": (None, [vp]),
+            "rsp_cholsol_f64": (cint, [csc, vp, C.c_int8]),
+            "rsp_lu_f64": (cint, [csc, vp, dbl, C.POINTER(vp)]),
+            "rsp_lu_L": (cint, [vp, csc]),
+            "rsp_lu_U": (cint, [vp, csc]),
+            "rsp_lu_pinv": (vp, [vp]),
+            "rsp_lu_solve_f64": (cint, [vp, vp, vp, i64, i64]),
+            "rsp_lu_free": (None, [vp]),
+            "rsp_lusol_f64": (cint, [csc, vp, C.c_int8, dbl]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        L._declared = sorted(sig)
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status == RSP_OK:
+        return
+    if status == RSP_NOT_POSITIVE_DEFINITE:
+        raise NotPositiveDefinite(lib().rsp_status_string(status).decode())
+    if status == RSP_NO_PIVOT:
+        raise NoPivot(lib().rsp_status_string(status).decode())
+    raise DeviceError(f"rsparse_hip status {status}: {lib().rsp_status_string(status).decode()}")
+
+
+def device_count():
+    return lib().rsp_device_count()
+
+
+def _vec(ptr, n, dtype):
+    if not ptr:
+        return None
+    ct = C.c_int64 if dtype == np.int64 else C.c_double
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).copy()
+
+
+class Sprs:
+    """rsparse::data::Sprs<f64> (src/data.rs:194-208): CSC with p: i64[n+1], i: u64[nnz], x: f64[nnz]."""
+
+    def __init__(self, m=0, n=0, p=None, i=None, x=None):
+        self.m, self.n = int(m), int(n)
+        self.p = np.ascontiguousarray(p if p is not None else np.zeros(n + 1), dtype=np.int64)
+        self.i = np.ascontiguousarray(i if i is not None else [], dtype=np.uint64)
+        self.x = np.ascontiguousarray(x if x is not None else [], dtype=np.float64)
+        self.nzmax = len(self.x)
+
+    @classmethod
+    def from_tuple(cls, t):
+        m, n, p, i, x = t
+        return cls(m, n, p, i, x)
+
+    @classmethod
+    def from_vec(cls, rows):
+        """Sprs::from_vec (src/data.rs:289-314): column by column, exact zeros dropped."""
+        a = np.asarray(rows, dtype=np.float64)
+        m, n = a.shape
+        mask = (a != 0.0).T  # column-major traversal
+        cols, rws = np.nonzero(mask)
+        p = np.zeros(n + 1, np.int64)
+        np.add.at(p, cols + 1, 1)
+        return cls(m, n, np.cumsum(p), rws, a.T[mask])
+
+    def as_tuple(self):
+        return (self.m, self.n, self.p, self.i.astype(np.int64), self.x)
+
+    def _view(self):
+        v = _Csc(self.nzmax, self.m, self.n, self.p.ctypes.data, self.i.ctypes.data, self.x.ctypes.data)
+        v._keep = self
+        return v
+
+
+def _as_sprs(a):
+    return a if isinstance(a, Sprs) else Sprs.from_tuple(a)
+
+
+def _one_shot(name, t, x):
+    t = _as_sprs(t)
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous):
+        raise TypeError("x must be a contiguous float64 numpy array (it is overwritten, like the reference's &mut [f64])")
+    _check(getattr(lib(), name)(C.byref(t._view()), x.ctypes.data))
+
+
+def lsolve(l, x):
+    """rsparse::lsolve (src/lib.rs:464): x <- L^-1 x, diagonal first in every column."""
+    _one_shot("rsp_lsolve_f64", l, x)
+
+
+def ltsolve(l, x):
+    """rsparse::ltsolve (src/lib.rs:505): x <- L^-T x."""
+    _one_shot("rsp_ltsolve_f64", l, x)
+
+
+def usolve(u, x):
+    """rsparse::usolve (src/lib.rs:1230): x <- U^-1 x, diagonal last in every column."""
+    _one_shot("rsp_usolve_f64", u, x)
+
+
+def utsolve(u, x):
+    """rsparse::utsolve (src/lib.rs:1271): x <- U^-T x."""
+    _one_shot("rsp_utsolve_f64", u, x)
+
+
+class Symb:
+    """rsparse::data::Symb (src/data.rs:1022-1038), owned by the library."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        L = lib()
+        self.n = L.rsp_symb_n(self._h)
+        self.pinv = _vec(L.rsp_symb_pinv(self._h), self.n, np.int64)
+        self.q = _vec(L.rsp_symb_q(self._h), self.n + 1, np.int64)
+        self.parent = _vec(L.rsp_symb_parent(self._h), self.n, np.int64)
+        self.cp = _vec(L.rsp_symb_cp(self._h), self.n + 1, np.int64)
+        self.lnz = L.rsp_symb_lnz(self._h)
+        self.unz = L.rsp_symb_unz(self._h)
+
+    @classmethod
+    def from_parts(cls, n, pinv=None, q=None, parent=None, cp=None):
+        def ptr(a):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, np.int64)
+            return a, a.ctypes.data
+        keep = [ptr(pinv), ptr(q), ptr(parent), ptr(cp)]
+        h = C.c_void_p()
+        _check(lib().rsp_symb_from_parts(n, keep[0][1], keep[1][1], keep[2][1], keep[3][1], C.byref(h)))
+        return cls(h.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rsp_symb_free(self._h)
+            self._h = None
+
+
+def schol(a, order):
+    """rsparse::schol (src/lib.rs:968): ordering + symbolic Cholesky analysis (host)."""
+    a = _as_sprs(a)
+    h = C.c_void_p()
+    _check(lib().rsp_schol(C.byref(a._view()), order, C.byref(h)))
+    return Symb(h.value)
+
+
+def sqr(a, order, qr=False):
+    """rsparse::sqr (src/lib.rs:1114), LU branch only (qr=true is outside the accelerated path)."""
+    if qr:
+        raise NotImplementedError("QR symbolic analysis is outside the numeric solve path (SURVEY.md section 8)")
+    a = _as_sprs(a)
+    h = C.c_void_p()
+    _check(lib().rsp_sqr_lu(C.byref(a._view()), order, C.byref(h)))
+    return Symb(h.value)
+
+
+def amd(a, order):
+    """rsparse's private amd (src/lib.rs:1292): returns the n+1-entry permutation or None."""
+    a = _as_sprs(a)
+    P = np.zeros(a.n + 1, np.int64)
+    has = C.c_int(0)
+    _check(lib().rsp_amd(C.byref(a._view()), order, P.ctypes.data, C.byref(has)))
+    return P if has.value else None
+
+
+class Nmrc:
+    """rsparse::data::Nmrc (src/data.rs:1064-1074)."""
+
+    def __init__(self, l=None, u=None, pinv=None):
+        self.l, self.u, self.pinv, self.b = l, u, pinv, []
+
+
+def chol(a, s):
+    """rsparse::chol (src/lib.rs:278): numeric Cholesky on the GPU; returns Nmrc with .l (pinv None)."""
+    a = _as_sprs(a)
+    n, lnz = a.n, int(s.cp[a.n])
+    Lp = np.zeros(n + 1, np.int64)
+    Li = np.zeros(max(lnz, 1), np.uint64)
+    Lx = np.zeros(max(lnz, 1), np.float64)
+    _check(lib().rsp_chol_f64(C.byref(a._view()), s._h, Lp.ctypes.data, Li.ctypes.data, Lx.ctypes.data))
+    return Nmrc(l=Sprs(n, n, Lp, Li[:lnz], Lx[:lnz]))
+
+
+def cholsol(a, b, order):
+    """rsparse::cholsol (src/lib.rs:377): b <- A^-1 b."""
+    a = _as_sprs(a)
+    assert b.dtype == np.float64 and b.flags.c_contiguous
+    _check(lib().rsp_cholsol_f64(C.byref(a._view()), b.ctypes.data, order))
+
+
+class LuHandle:
+    def __init__(self, handle, symb):
+        self._h = C.c_void_p(handle)
+        self._s = symb
+
+    def _mat(self, getter):
+        v = _Csc()
+        _check(getter(self._h, C.byref(v)))
+        nz = v.nzmax
+        p = _vec(v.p, v.n + 1, np.int64)
+        i = _vec(v.i, nz, np.int64) if nz else np.zeros(0, np.int64)
+        x = _vec(v.x, nz, np.float64) if nz else np.zeros(0)
+        return Sprs(v.m, v.n, p, i, x)
+
+    @property
+    def l(self):
+        return self._mat(lib().rsp_lu_L)
+
+    @property
+    def u(self):
+        return self._mat(lib().rsp_lu_U)
+
+    @property
+    def pinv(self):
+        return _vec(lib().rsp_lu_pinv(self._h), self._s.n, np.int64)
+
+    def solve(self, B):
+        """B: float64, shape (n,) or Fortran-ordered (n, nrhs); overwritten with A^-1 B."""
+        n = self._s.n
+        nrhs = 1 if B.ndim == 1 else B.shape[1]
+        assert B.dtype == np.float64 and (B.ndim == 1 or B.flags.f_contiguous)
+        _check(lib().rsp_lu_solve_f64(self._h, self._s._h, B.ctypes.data, n, nrhs))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rsp_lu_free(self._h)
+            self._h = None
+
+
+def lu(a, s, tol):
+    """rsparse::lu (src/lib.rs:519): host LU with the reference's pivot rule; returns a handle with .l .u .pinv."""
+    a = _as_sprs(a)
+    h = C.c_void_p()
+    _check(lib().rsp_lu_f64(C.byref(a._view()), s._h, tol, C.byref(h)))
+    return LuHandle(h.value, s)
+
+
+def lusol(a, b, order, tol):
+    """rsparse::lusol (src/lib.rs:672): b <- A^-1 b."""
+    a = _as_sprs(a)
+    assert b.dtype == np.float64 and b.flags.c_contiguous
+    _check(lib().rsp_lusol_f64(C.byref(a._view()), b.ctypes.data, order, tol))
+
+
+class TriHandle:
+    """Analyse-once / solve-many triangular solver (rsp_tri_*)."""
+
+    def __init__(self, t, kind):
+        t = _as_sprs(t)
+        h = C.c_void_p()
+        _check(lib().rsp_tri_analyze(C.byref(t._view()), kind, C.byref(h)))
+        self._h, self.n, self.kind = h, t.n, kind
+
+    def solve(self, X):
+        """X float64: (n,) or Fortran-ordered (n, nrhs) host array, overwritten."""
+        nrhs = 1 if X.ndim == 1 else X.shape[1]
+        assert X.dtype == np.float64 and (X.ndim == 1 or X.flags.f_contiguous)
+        _check(lib().rsp_tri_solve_f64(self._h, X.ctypes.data, self.n, nrhs))
+
+    def solve_dev(self, ptr, layout, ld, nrhs, stream=None):
+        _check(lib().rsp_tri_solve_dev_f64(self._h, ptr, layout, ld, nrhs, stream))
+
+    def info(self):
+        a = np.zeros(8, np.int64)
+        _check(lib().rsp_tri_info(self._h, a.ctypes.data))
+        keys = ("n", "nnz", "row_levels", "tasks", "launches", "device_bytes", "bytes_1rhs", "longest_task")
+        return dict(zip(keys, a.tolist()))
+
+    def levels(self):
+        a = np.zeros(self.n, np.int64)
+        _check(lib().rsp_tri_levels(self._h, a.ctypes.data))
+        return a
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rsp_tri_free(self._h)
+            self._h = None
+
+
+class CholHandle:
+    """Device-resident Cholesky factor (rsp_chol_*): factor once, solve many."""
+
+    def __init__(self, a, s):
+        a = _as_sprs(a)
+        h = C.c_void_p()
+        _check(lib().rsp_chol_factor_f64(C.byref(a._view()), s._h, C.byref(h)))
+        self._h, self.n = h, a.n
+
+    def solve(self, B):
+        nrhs = 1 if B.ndim == 1 else B.shape[1]
+        assert B.dtype == np.float64 and (B.ndim == 1 or B.flags.f_contiguous)
+        _check(lib().rsp_chol_solve_f64(self._h, B.ctypes.data, self.n, nrhs))
+
+    def solve_dev(self, ptr, layout, ld, nrhs, permute=True, stream=None):
+        _check(lib().rsp_chol_solve_dev_f64(self._h, ptr, layout, ld, nrhs, 1 if permute else 0, stream))
+
+    def factor(self):
+        lnz = lib().rsp_chol_lnz(self._h)
+        Lp = np.zeros(self.n + 1, np.int64)
+        Li = np.zeros(max(lnz, 1), np.uint64)
+        Lx = np.zeros(max(lnz, 1))
+        _check(lib().rsp_chol_get_factor(self._h, Lp.ctypes.data, Li.ctypes.data, Lx.ctypes.data))
+        return Sprs(self.n, self.n, Lp, Li[:lnz], Lx[:lnz])
+
+    def info(self):
+        a = np.zeros(10, np.int64)
+        _check(lib().rsp_chol_info(self._h, a.ctypes.data))
+        keys = ("n", "lnz", "supernodes", "chol_levels", "flops", "bytes_chol", "lsolve_launches", "lsolve_tasks",
+                "ltsolve_launches", "ltsolve_tasks")
+        d = dict(zip(keys, a.tolist()))
+        d["factor_ms"] = lib().rsp_chol_factor_ms(self._h)
+        return d
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rsp_chol_free(self._h)
+            self._h = None

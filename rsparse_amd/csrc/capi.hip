@@ -1,0 +1,408 @@
+// extern "C" surface of librsparse_hip.so (declared in include/rsparse_hip.h).
+// Nothing throws across this boundary: every entry point maps exceptions to an rsp_status.
+#include <cstring>
+#include <new>
+
+#include "../../include/rsparse_hip.h"
+#include "device/chol_engine.hpp"
+#include "device/engine.hpp"
+
+using namespace rsp;
+
+struct rsp_tri {
+    TriSolver solver;
+};
+struct rsp_symb {
+    Symbolic s;
+};
+struct rsp_chol {
+    CholFactor f;
+};
+struct rsp_lu {
+    LuFactors f;
+    std::unique_ptr<TriSolver> lower, upper;  // built on first solve
+};
+
+namespace {
+
+CscView view_of(const rsp_csc_f64 *A)
+{
+    return CscView{A->m, A->n, A->p, reinterpret_cast<const int64_t *>(A->i), A->x};
+}
+
+bool sane(const rsp_csc_f64 *A)
+{
+    if (!A || A->n < 0 || A->m < 0 || !A->p) return false;
+    if (A->p[0] != 0 || A->p[A->n] < 0) return false;
+    if (A->p[A->n] > 0 && (!A->i || !A->x)) return false;
+    return true;
+}
+
+bool sane_indices(const rsp_csc_f64 *A)
+{
+    if (!sane(A)) return false;
+    for (int64_t j = 0; j < A->n; ++j)
+        if (A->p[j + 1] < A->p[j]) return false;
+    const int64_t nz = A->p[A->n];
+    for (int64_t e = 0; e < nz; ++e)
+        if (A->i[e] >= (uint64_t)A->m) return false;
+    return true;
+}
+
+template <class F>
+int guarded(F &&f)
+{
+    try {
+        return f();
+    } catch (const DeviceError &) {
+        return RSP_DEVICE_ERROR;
+    } catch (const std::bad_alloc &) {
+        return RSP_DEVICE_ERROR;
+    } catch (...) {
+        return RSP_BAD_INPUT;
+    }
+}
+
+int require_device()
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RSP_DEVICE_ERROR;
+    return RSP_OK;
+}
+
+int one_shot(const rsp_csc_f64 *T, int kind, double *x)
+{
+    if (!sane(T) || !x) return RSP_BAD_INPUT;
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        TriSolver s;
+        if (int st = s.analyze(view_of(T), kind)) return st;
+        s.solve_host(x, T->n, 1);
+        return (int)RSP_OK;
+    });
+}
+
+// x(P) = b for every right-hand side column (ipvec, lib.rs:2151-2159); P == nullptr is the identity
+void scatter_rows(int64_t n, const int64_t *p, const double *b, double *x, int64_t ld, int64_t nrhs)
+{
+    for (int64_t r = 0; r < nrhs; ++r)
+        for (int64_t k = 0; k < n; ++k) x[(p ? p[k] : k) + r * n] = b[k + r * ld];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rsp_status_string(int status)
+{
+    switch (status) {
+        case RSP_OK: return "ok";
+        case RSP_NOT_POSITIVE_DEFINITE:
+            return "Could not complete Cholesky factorization. Please provide a positive definite matrix";
+        case RSP_NO_PIVOT: return "Could not find a pivot";
+        case RSP_BAD_INPUT: return "bad input";
+        case RSP_DEVICE_ERROR: return "HIP device error (is a gfx950 GPU visible?)";
+        default: return "unknown status";
+    }
+}
+
+int rsp_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int rsp_set_device(int device) { return hipSetDevice(device) == hipSuccess ? RSP_OK : RSP_DEVICE_ERROR; }
+
+int rsp_lsolve_f64(const rsp_csc_f64 *L, double *x) { return one_shot(L, RSP_LSOLVE, x); }
+int rsp_ltsolve_f64(const rsp_csc_f64 *L, double *x) { return one_shot(L, RSP_LTSOLVE, x); }
+int rsp_usolve_f64(const rsp_csc_f64 *U, double *x) { return one_shot(U, RSP_USOLVE, x); }
+int rsp_utsolve_f64(const rsp_csc_f64 *U, double *x) { return one_shot(U, RSP_UTSOLVE, x); }
+
+int rsp_tri_analyze(const rsp_csc_f64 *T, int kind, rsp_tri **out)
+{
+    if (!sane(T) || !out) return RSP_BAD_INPUT;
+    *out = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_tri> h(new rsp_tri);
+        if (int st = h->solver.analyze(view_of(T), kind)) return st;
+        *out = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_tri_solve_f64(rsp_tri *h, double *X, int64_t ldx, int64_t nrhs)
+{
+    if (!h || !X || nrhs < 0 || ldx < h->solver.n()) return RSP_BAD_INPUT;
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        h->solver.solve_host(X, ldx, nrhs);
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_t nrhs, void *stream)
+{
+    if (!h || !dX || nrhs < 0 || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR)) return RSP_BAD_INPUT;
+    if (layout == RSP_COL_MAJOR ? ld < h->solver.n() : ld < nrhs) return RSP_BAD_INPUT;
+    return guarded([&] {
+        h->solver.solve_device(dX, layout, ld, nrhs, (hipStream_t)stream);
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_tri_info(const rsp_tri *h, int64_t *info)
+{
+    if (!h || !info) return RSP_BAD_INPUT;
+    const TriSolver &s = h->solver;
+    const TriProgram &P = s.multi_program();
+    info[0] = s.n();
+    info[1] = s.nnz();
+    info[2] = s.num_row_levels();
+    info[3] = P.ntasks;
+    info[4] = P.nlevels;
+    info[5] = (int64_t)P.device_bytes();
+    info[6] = s.algorithmic_bytes(1);
+    info[7] = P.longest_task;
+    return RSP_OK;
+}
+
+int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row)
+{
+    if (!h || !level_of_row) return RSP_BAD_INPUT;
+    const auto &lv = h->solver.level_of_row();
+    std::memcpy(level_of_row, lv.data(), lv.size() * sizeof(int64_t));
+    return RSP_OK;
+}
+
+void rsp_tri_free(rsp_tri *h) { delete h; }
+
+// ---- symbolic -----------------------------------------------------------------------------------
+
+int rsp_schol(const rsp_csc_f64 *A, int8_t order, rsp_symb **S)
+{
+    if (!sane_indices(A) || !S || A->m != A->n) return RSP_BAD_INPUT;
+    *S = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_symb> h(new rsp_symb);
+        h->s = symbolic_cholesky(view_of(A), order);
+        *S = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_sqr_lu(const rsp_csc_f64 *A, int8_t order, rsp_symb **S)
+{
+    if (!sane_indices(A) || !S) return RSP_BAD_INPUT;
+    *S = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_symb> h(new rsp_symb);
+        h->s = symbolic_lu(view_of(A), order);
+        *S = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_symb_from_parts(int64_t n, const int64_t *pinv, const int64_t *q, const int64_t *parent, const int64_t *cp, rsp_symb **S)
+{
+    if (n < 0 || !S) return RSP_BAD_INPUT;
+    *S = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_symb> h(new rsp_symb);
+        Symbolic &s = h->s;
+        s.n = n;
+        if (pinv) { s.has_pinv = true; s.pinv.assign(pinv, pinv + n); }
+        if (q) { s.has_q = true; s.q.assign(q, q + n); s.q.push_back(n); }
+        if (parent) s.parent.assign(parent, parent + n);
+        if (cp) { s.cp.assign(cp, cp + n + 1); s.lnz = s.unz = cp[n]; }
+        *S = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int64_t rsp_symb_n(const rsp_symb *S) { return S ? S->s.n : 0; }
+const int64_t *rsp_symb_pinv(const rsp_symb *S) { return (S && S->s.has_pinv) ? S->s.pinv.data() : nullptr; }
+const int64_t *rsp_symb_q(const rsp_symb *S) { return (S && S->s.has_q) ? S->s.q.data() : nullptr; }
+const int64_t *rsp_symb_parent(const rsp_symb *S) { return (S && !S->s.parent.empty()) ? S->s.parent.data() : nullptr; }
+const int64_t *rsp_symb_cp(const rsp_symb *S) { return (S && !S->s.cp.empty()) ? S->s.cp.data() : nullptr; }
+int64_t rsp_symb_lnz(const rsp_symb *S) { return S ? S->s.lnz : 0; }
+int64_t rsp_symb_unz(const rsp_symb *S) { return S ? S->s.unz : 0; }
+void rsp_symb_free(rsp_symb *S) { delete S; }
+
+int rsp_amd(const rsp_csc_f64 *A, int8_t order, int64_t *P, int *has_perm)
+{
+    if (!sane_indices(A) || !P || !has_perm) return RSP_BAD_INPUT;
+    return guarded([&] {
+        std::vector<int64_t> perm;
+        *has_perm = approximate_minimum_degree(view_of(A), order, perm) ? 1 : 0;
+        if (*has_perm) std::memcpy(P, perm.data(), perm.size() * sizeof(int64_t));
+        return (int)RSP_OK;
+    });
+}
+
+// ---- Cholesky -----------------------------------------------------------------------------------
+
+int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F)
+{
+    if (!sane_indices(A) || !S || !F || A->m != A->n || S->s.n != A->n || S->s.parent.size() != (size_t)A->n ||
+        S->s.cp.size() != (size_t)A->n + 1)
+        return RSP_BAD_INPUT;
+    *F = nullptr;
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        std::unique_ptr<rsp_chol> h(new rsp_chol);
+        if (int st = h->f.analyze(view_of(A), S->s)) return st;
+        if (int st = h->f.factorize(view_of(A))) return st;
+        *F = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_chol_f64(const rsp_csc_f64 *A, const rsp_symb *S, int64_t *Lp, uint64_t *Li, double *Lx)
+{
+    if (!Lp || !Li || !Lx) return RSP_BAD_INPUT;
+    rsp_chol *F = nullptr;
+    int st = rsp_chol_factor_f64(A, S, &F);
+    if (st == RSP_OK) st = rsp_chol_get_factor(F, Lp, Li, Lx);
+    rsp_chol_free(F);
+    return st;
+}
+
+int rsp_chol_get_factor(const rsp_chol *F, int64_t *Lp, uint64_t *Li, double *Lx)
+{
+    if (!F || !Lp || !Li || !Lx) return RSP_BAD_INPUT;
+    return guarded([&] {
+        F->f.download(Lp, reinterpret_cast<int64_t *>(Li), Lx);
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs)
+{
+    if (!F || !B || nrhs < 0 || ldb < F->f.n()) return RSP_BAD_INPUT;
+    return guarded([&] {
+        F->f.solve_host(B, ldb, nrhs);
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int64_t nrhs, int permute, void *stream)
+{
+    if (!F || !dB || nrhs < 0 || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR)) return RSP_BAD_INPUT;
+    if (layout == RSP_COL_MAJOR ? ld < F->f.n() : ld < nrhs) return RSP_BAD_INPUT;
+    return guarded([&] {
+        F->f.solve_device(dB, layout, ld, nrhs, permute != 0, (hipStream_t)stream);
+        return (int)RSP_OK;
+    });
+}
+
+int64_t rsp_chol_lnz(const rsp_chol *F) { return F ? F->f.lnz() : 0; }
+
+int rsp_chol_info(const rsp_chol *F, int64_t *info)
+{
+    if (!F || !info) return RSP_BAD_INPUT;
+    F->f.info(info);
+    return RSP_OK;
+}
+
+double rsp_chol_factor_ms(const rsp_chol *F) { return F ? F->f.factor_ms() : 0.0; }
+
+void rsp_chol_free(rsp_chol *F) { delete F; }
+
+int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
+{
+    if (!sane_indices(A) || !b || A->m != A->n) return RSP_BAD_INPUT;
+    rsp_symb *S = nullptr;
+    rsp_chol *F = nullptr;
+    int st = rsp_schol(A, order, &S);                    // ordering and symbolic analysis (host)
+    if (st == RSP_OK) st = rsp_chol_factor_f64(A, S, &F);  // numeric Cholesky (GPU)
+    if (st == RSP_OK) st = rsp_chol_solve_f64(F, b, A->n, 1);  // P, lsolve, ltsolve, P' (GPU)
+    rsp_chol_free(F);
+    rsp_symb_free(S);
+    return st;
+}
+
+// ---- LU -----------------------------------------------------------------------------------------
+
+int rsp_lu_f64(const rsp_csc_f64 *A, const rsp_symb *S, double tol, rsp_lu **N)
+{
+    if (!sane_indices(A) || !S || !N || A->m != A->n || S->s.n != A->n) return RSP_BAD_INPUT;
+    *N = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_lu> h(new rsp_lu);
+        if (int st = sparse_lu(view_of(A), S->s.has_q ? S->s.q.data() : nullptr, tol, h->f)) return st;
+        *N = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+static void fill_view(const Csc &M, rsp_csc_f64 *out)
+{
+    out->nzmax = M.p[M.n];
+    out->m = M.m;
+    out->n = M.n;
+    out->p = M.p.data();
+    out->i = reinterpret_cast<const uint64_t *>(M.i.data());
+    out->x = M.x.data();
+}
+
+int rsp_lu_L(const rsp_lu *N, rsp_csc_f64 *L)
+{
+    if (!N || !L) return RSP_BAD_INPUT;
+    fill_view(N->f.L, L);
+    return RSP_OK;
+}
+int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U)
+{
+    if (!N || !U) return RSP_BAD_INPUT;
+    fill_view(N->f.U, U);
+    return RSP_OK;
+}
+const int64_t *rsp_lu_pinv(const rsp_lu *N) { return N ? N->f.pinv.data() : nullptr; }
+
+int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs)
+{
+    if (!N || !S || !B || nrhs < 0 || ldb < N->f.L.n) return RSP_BAD_INPUT;
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        const int64_t n = N->f.L.n;
+        if (!N->lower) {
+            std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
+            if (int st = lo->analyze(N->f.L.view(), RSP_LSOLVE)) return st;
+            if (int st = up->analyze(N->f.U.view(), RSP_USOLVE)) return st;
+            N->lower = std::move(lo);
+            N->upper = std::move(up);
+        }
+        // x = P b (host gather, 16 MB per million unknowns), L and U solves on the GPU, b = Q x
+        std::vector<double> x((size_t)n * (size_t)nrhs);
+        scatter_rows(n, N->f.pinv.data(), B, x.data(), ldb, nrhs);
+        DeviceBuffer<double> d(x.size());
+        d.upload(x);
+        N->lower->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
+        N->upper->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
+        RSP_HIP(hipDeviceSynchronize());
+        d.download(x.data(), x.size());
+        const int64_t *q = S->s.has_q ? S->s.q.data() : nullptr;
+        for (int64_t r = 0; r < nrhs; ++r)
+            for (int64_t k = 0; k < n; ++k) B[(q ? q[k] : k) + r * ldb] = x[k + r * n];
+        return (int)RSP_OK;
+    });
+}
+
+void rsp_lu_free(rsp_lu *N) { delete N; }
+
+int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol)
+{
+    if (!sane_indices(A) || !b || A->m != A->n) return RSP_BAD_INPUT;
+    rsp_symb *S = nullptr;
+    rsp_lu *N = nullptr;
+    int st = rsp_sqr_lu(A, order, &S);               // ordering (host)
+    if (st == RSP_OK) st = rsp_lu_f64(A, S, tol, &N);  // numeric LU (host, pivot sequence bit-exact)
+    if (st == RSP_OK) st = rsp_lu_solve_f64(N, S, b, A->n, 1);  // lsolve + usolve (GPU)
+    rsp_lu_free(N);
+    rsp_symb_free(S);
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Device-side objects of librsparse_hip: RAII buffers, the triangular-solve engine and the numeric
+// Cholesky engine.  Everything here runs on the GPU; there is no CPU fallback for numeric work.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../host/sparse.hpp"
+
+namespace rsp {
+
+struct DeviceError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define RSP_HIP(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            throw ::rsp::DeviceError(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+template <class T>
+class DeviceBuffer {
+   public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t count) { resize(count); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    DeviceBuffer(DeviceBuffer &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept
+    {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    void resize(size_t count)
+    {
+        if (count <= n_ && p_) return;
+        release();
+        RSP_HIP(hipMalloc((void **)&p_, (count ? count : 1) * sizeof(T)));
+        n_ = count;
+    }
+    void upload(const T *src, size_t count)
+    {
+        resize(count);
+        if (count) RSP_HIP(hipMemcpy(p_, src, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void upload(const std::vector<T> &v) { upload(v.data(), v.size()); }
+    void download(T *dst, size_t count) const
+    {
+        if (count) RSP_HIP(hipMemcpy(dst, p_, count * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    T *get() const { return p_; }
+    size_t size() const { return n_; }
+    size_t bytes() const { return n_ * sizeof(T); }
+
+   private:
+    void release()
+    {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    T *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// One level-scheduled program (see solve_kernels.hip) resident on the device.
+struct TriProgram {
+    i64 ntasks = 0, nlevels = 0, longest_task = 0;
+    DeviceBuffer<int32_t> task_ptr, op_row, op_ptr, ent_idx;
+    DeviceBuffer<double> op_diag, ent_val;
+    std::vector<std::pair<int, int>> levels;  // (first task, number of tasks)
+    size_t device_bytes() const
+    {
+        return task_ptr.bytes() + op_row.bytes() + op_ptr.bytes() + ent_idx.bytes() + op_diag.bytes() + ent_val.bytes();
+    }
+};
+
+// Analyse-once / solve-many engine for one triangular factor and one of the four solve kinds.
+class TriSolver {
+   public:
+    // throws DeviceError; returns kOk / kBadInput
+    int analyze(const CscView &T, int kind);
+    // dX device pointer. layout: 0 column-major, 1 row-major (include/rsparse_hip.h).  Asynchronous on `stream`.
+    void solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream_t stream);
+    // X host column-major
+    void solve_host(double *X, i64 ldx, i64 nrhs);
+
+    i64 n() const { return n_; }
+    i64 nnz() const { return nnz_; }
+    const std::vector<i64> &level_of_row() const { return level_of_row_; }
+    i64 num_row_levels() const { return num_row_levels_; }
+    const TriProgram &multi_program() const { return multi_; }
+    const TriProgram &single_program() const { return single_; }
+    i64 algorithmic_bytes(i64 nrhs) const { return nnz_ * 12 + (n_ + 1) * 4 + 16 * n_ * nrhs; }
+
+   private:
+    void build_program(i64 max_task_entries, TriProgram &P);
+    void run_multi(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
+    void run_single(double *x, hipStream_t stream);
+
+    i64 n_ = 0, nnz_ = 0, num_row_levels_ = 0;
+    GatherForm G_;  // kept on the host so the second program can be built lazily
+    std::vector<i64> level_of_row_;
+    TriProgram multi_, single_;
+    bool have_multi_ = false, have_single_ = false;
+    DeviceBuffer<double> work_;  // row-major staging for column-major callers
+};
+
+// tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)
+constexpr i64 kTaskEntriesMulti = 2048;
+constexpr i64 kTaskEntriesSingle = 512;
+
+}  // namespace rsp

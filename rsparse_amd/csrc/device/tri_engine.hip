@@ -1,0 +1,135 @@
+// TriSolver: uploads a triangular factor in execution order and runs the level-scheduled kernels.
+#include "engine.hpp"
+#include "solve_kernels.hip"
+
+namespace rsp {
+
+int TriSolver::analyze(const CscView &T, int kind)
+{
+    const int st = build_gather_form(T, kind, G_);
+    if (st != kOk) return st;
+    n_ = G_.n;
+    nnz_ = (i64)G_.idx.size() + n_;
+    // canonical level sets (reported through rsp_tri_levels for bit-exact comparison)
+    Schedule S = build_schedule(G_, 0);
+    level_of_row_ = std::move(S.level_of_row);
+    num_row_levels_ = S.num_row_levels;
+    return kOk;
+}
+
+void TriSolver::build_program(i64 max_task_entries, TriProgram &P)
+{
+    const Schedule S = build_schedule(G_, max_task_entries);
+    const i64 ntasks = (i64)S.task_first.size();
+    std::vector<int32_t> task_ptr(ntasks + 1, 0), op_row(n_), op_ptr(n_ + 1, 0), ent_idx(G_.idx.size());
+    std::vector<double> op_diag(n_), ent_val(G_.val.size());
+    i64 op = 0, ent = 0;
+    for (i64 t = 0; t < ntasks; ++t) {
+        task_ptr[t] = (int32_t)op;
+        for (i64 s = 0; s < S.task_rows[t]; ++s) {
+            const i64 r = G_.descending ? S.task_first[t] - s : S.task_first[t] + s;
+            op_row[op] = (int32_t)r;
+            op_diag[op] = G_.diag[r];
+            op_ptr[op] = (int32_t)ent;
+            const i64 len = G_.ptr[r + 1] - G_.ptr[r];
+            std::copy(G_.idx.begin() + G_.ptr[r], G_.idx.begin() + G_.ptr[r + 1], ent_idx.begin() + ent);
+            std::copy(G_.val.begin() + G_.ptr[r], G_.val.begin() + G_.ptr[r + 1], ent_val.begin() + ent);
+            ent += len;
+            ++op;
+        }
+    }
+    task_ptr[ntasks] = (int32_t)op;
+    op_ptr[n_] = (int32_t)ent;
+    P.ntasks = ntasks;
+    P.nlevels = (i64)S.level_ptr.size() - 1;
+    P.longest_task = S.longest_task;
+    P.levels.clear();
+    for (i64 l = 0; l < P.nlevels; ++l)
+        P.levels.emplace_back((int)S.level_ptr[l], (int)(S.level_ptr[l + 1] - S.level_ptr[l]));
+    P.task_ptr.upload(task_ptr);
+    P.op_row.upload(op_row);
+    P.op_ptr.upload(op_ptr);
+    P.op_diag.upload(op_diag);
+    P.ent_idx.upload(ent_idx);
+    P.ent_val.upload(ent_val);
+}
+
+static dev::TriArrays arrays_of(const TriProgram &P)
+{
+    return dev::TriArrays{P.task_ptr.get(), P.op_row.get(), P.op_ptr.get(), P.op_diag.get(), P.ent_idx.get(), P.ent_val.get()};
+}
+
+void TriSolver::run_multi(double *X, i64 ld, i64 nrhs, hipStream_t stream)
+{
+    if (!have_multi_) {
+        build_program(kTaskEntriesMulti, multi_);
+        have_multi_ = true;
+    }
+    const dev::TriArrays A = arrays_of(multi_);
+    const int wpb = 4;  // wavefronts per 256-thread block
+    for (const auto &lv : multi_.levels) {
+        // widest per-lane vector that still gives the chip enough wavefronts for this level
+        int V = 1;
+        if (nrhs % 4 == 0 && (i64)lv.second * ((nrhs + 255) / 256) >= 2048) V = 4;
+        else if (nrhs % 2 == 0 && (i64)lv.second * ((nrhs + 127) / 128) >= 2048) V = 2;
+        const int nchunks = (int)((nrhs + 64 * V - 1) / (64 * V));
+        const i64 waves = (i64)lv.second * nchunks;
+        const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+        if (V == 4)
+            hipLaunchKernelGGL(dev::solve_level_multi<4>, grid, block, 0, stream, A, lv.first, lv.second, X, ld, (int)nrhs, nchunks);
+        else if (V == 2)
+            hipLaunchKernelGGL(dev::solve_level_multi<2>, grid, block, 0, stream, A, lv.first, lv.second, X, ld, (int)nrhs, nchunks);
+        else
+            hipLaunchKernelGGL(dev::solve_level_multi<1>, grid, block, 0, stream, A, lv.first, lv.second, X, ld, (int)nrhs, nchunks);
+    }
+    RSP_HIP(hipGetLastError());
+}
+
+void TriSolver::run_single(double *x, hipStream_t stream)
+{
+    if (!have_single_) {
+        build_program(kTaskEntriesSingle, single_);
+        have_single_ = true;
+    }
+    const dev::TriArrays A = arrays_of(single_);
+    const int wpb = 4;
+    for (const auto &lv : single_.levels) {
+        const dim3 grid((unsigned)((lv.second + wpb - 1) / wpb)), block(64 * wpb);
+        hipLaunchKernelGGL(dev::solve_level_single, grid, block, 0, stream, A, lv.first, lv.second, x);
+    }
+    RSP_HIP(hipGetLastError());
+}
+
+void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0 || n_ == 0) return;
+    if (nrhs == 1 && (layout == 0 || ld == 1)) {
+        run_single(dX, stream);
+        return;
+    }
+    if (layout == 1) {
+        run_multi(dX, ld, nrhs, stream);
+        return;
+    }
+    // column-major caller: stage through a row-major workspace (two extra passes over X)
+    work_.resize((size_t)n_ * (size_t)nrhs);
+    const dim3 grid((unsigned)((n_ + 31) / 32), (unsigned)((nrhs + 31) / 32)), block(256);
+    hipLaunchKernelGGL(dev::colmajor_to_rowmajor, grid, block, 0, stream, dX, ld, work_.get(), nrhs, n_, (int)nrhs,
+                       (const int64_t *)nullptr, 0);
+    run_multi(work_.get(), nrhs, nrhs, stream);
+    hipLaunchKernelGGL(dev::rowmajor_to_colmajor, grid, block, 0, stream, work_.get(), nrhs, dX, ld, n_, (int)nrhs,
+                       (const int64_t *)nullptr, 0);
+    RSP_HIP(hipGetLastError());
+}
+
+void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
+{
+    if (nrhs <= 0 || n_ == 0) return;
+    DeviceBuffer<double> d((size_t)n_ * (size_t)nrhs);
+    RSP_HIP(hipMemcpy2D(d.get(), n_ * sizeof(double), X, ldx * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyHostToDevice));
+    solve_device(d.get(), 0, n_, nrhs, nullptr);
+    RSP_HIP(hipDeviceSynchronize());
+    RSP_HIP(hipMemcpy2D(X, ldx * sizeof(double), d.get(), n_ * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyDeviceToHost));
+}
+
+}  // namespace rsp

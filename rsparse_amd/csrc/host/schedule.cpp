@@ -1,0 +1,113 @@
+// Turns a CSC triangular factor into the "gather" form the kernels consume, and builds the level
+// schedule (integer-only, host).  No counterpart in the reference, whose solves are bare sequential
+// loops (/root/reference/src/lib.rs:464-471, 505-512, 1230-1237, 1271-1278); the dependency structure
+// encoded here is exactly the order those loops impose.
+#include <algorithm>
+#include <limits>
+
+#include "sparse.hpp"
+
+namespace rsp {
+
+int build_gather_form(const CscView &T, int kind, GatherForm &G)
+{
+    const i64 n = T.n;
+    if (T.m != n || kind < 0 || kind > 3) return kBadInput;
+    if (n >= std::numeric_limits<int32_t>::max() || T.nnz() >= std::numeric_limits<int32_t>::max()) return kBadInput;
+    const bool lower_storage = (kind == 0 || kind == 1);  // L: diagonal first; U: diagonal last
+    const bool by_rows = (kind == 0 || kind == 2);        // lsolve/usolve gather along ROWS of the stored factor
+    G.n = n;
+    G.descending = (kind == 1 || kind == 2);
+    G.diag.assign(n, 0.0);
+    G.ptr.assign(n + 1, 0);
+    // validate + diagonal + per-unknown entry counts
+    for (i64 j = 0; j < n; ++j) {
+        const i64 b = T.p[j], e = T.p[j + 1];
+        if (e <= b || b < 0 || e > T.nnz()) return kBadInput;  // the reference indexes the diagonal unconditionally
+        const i64 dpos = lower_storage ? b : e - 1;
+        G.diag[j] = T.x[dpos];
+        for (i64 p = (lower_storage ? b + 1 : b); p < (lower_storage ? e : e - 1); ++p) {
+            const i64 i = T.i[p];
+            // off-diagonal entries must lie strictly inside the triangle, otherwise the loops of the reference
+            // do not describe a triangular solve (it would silently compute something else)
+            if (lower_storage ? !(i > j && i < n) : !(i >= 0 && i < j)) return kBadInput;
+            G.ptr[(by_rows ? i : j) + 1]++;
+        }
+    }
+    for (i64 r = 0; r < n; ++r) G.ptr[r + 1] += G.ptr[r];
+    const i64 nz = G.ptr[n];
+    G.idx.resize(nz);
+    G.val.resize(nz);
+    std::vector<i64> fill(G.ptr.begin(), G.ptr.end() - 1);
+    // visit source columns in the order the reference's loop visits them, so each unknown accumulates its terms
+    // in the reference's order: ascending j for lsolve/utsolve, descending j for ltsolve/usolve
+    for (i64 t = 0; t < n; ++t) {
+        const i64 j = G.descending ? n - 1 - t : t;
+        const i64 b = T.p[j], e = T.p[j + 1];
+        for (i64 p = (lower_storage ? b + 1 : b); p < (lower_storage ? e : e - 1); ++p) {
+            const i64 i = T.i[p];
+            const i64 q = fill[by_rows ? i : j]++;
+            G.idx[q] = (int32_t)(by_rows ? j : i);
+            G.val[q] = T.x[p];
+        }
+    }
+    return kOk;
+}
+
+Schedule build_schedule(const GatherForm &G, i64 max_task_entries)
+{
+    const i64 n = G.n;
+    Schedule S;
+    S.level_of_row.assign(n, 0);
+    std::vector<int32_t> task_of(n, -1);
+    std::vector<int32_t> task_level;  // level of each task, in creation order
+    std::vector<int32_t> first, rows;
+    i64 cur = -1, cur_entries = 0;
+    for (i64 t = 0; t < n; ++t) {
+        const i64 r = G.descending ? n - 1 - t : t;
+        i64 row_level = 0;   // canonical level of the unknown
+        i64 need = 0;        // lowest task level that satisfies the dependencies outside the current task
+        bool chained = false;
+        for (i64 p = G.ptr[r]; p < G.ptr[r + 1]; ++p) {
+            const i64 d = G.idx[p];
+            row_level = std::max(row_level, S.level_of_row[d] + 1);
+            if (task_of[d] == cur) chained = true;
+            else need = std::max<i64>(need, task_level[task_of[d]] + 1);
+        }
+        S.level_of_row[r] = row_level;
+        S.num_row_levels = std::max(S.num_row_levels, row_level + 1);
+        const i64 nent = G.ptr[r + 1] - G.ptr[r];
+        const bool fits = cur >= 0 && cur_entries + nent <= max_task_entries;
+        if (fits && need <= task_level[cur] && (chained || need == task_level[cur])) {
+            rows[cur]++;
+            cur_entries += nent;
+        } else {
+            if (cur >= 0 && chained) need = std::max<i64>(need, task_level[cur] + 1);
+            cur = (i64)first.size();
+            first.push_back((int32_t)r);
+            rows.push_back(1);
+            task_level.push_back((int32_t)need);
+            cur_entries = nent;
+        }
+        task_of[r] = (int32_t)cur;
+    }
+    // bucket tasks by level (stable: creation order inside a level)
+    i64 nlevels = 0;
+    for (int32_t l : task_level) nlevels = std::max<i64>(nlevels, l + 1);
+    S.level_ptr.assign(nlevels + 1, 0);
+    for (int32_t l : task_level) S.level_ptr[l + 1]++;
+    for (i64 l = 0; l < nlevels; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
+    std::vector<i64> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
+    const i64 ntasks = (i64)first.size();
+    S.task_first.resize(ntasks);
+    S.task_rows.resize(ntasks);
+    for (i64 k = 0; k < ntasks; ++k) {
+        const i64 q = fill[task_level[k]]++;
+        S.task_first[q] = first[k];
+        S.task_rows[q] = rows[k];
+        S.longest_task = std::max<i64>(S.longest_task, rows[k]);
+    }
+    return S;
+}
+
+}  // namespace rsp

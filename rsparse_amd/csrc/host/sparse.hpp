@@ -1,0 +1,112 @@
+// Host-side data model and symbolic layer of librsparse_hip (product code, runs on the CPU by design:
+// north_star keeps ordering / etree / patterns / LU pivoting on the host).
+// Mirrors rsparse's src/data.rs types; every routine cites the reference lines whose RESULT it must
+// reproduce.  Independent of oracle/ (which is test infrastructure and never linked here).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace rsp {
+
+using i64 = int64_t;
+
+// borrowed CSC view == the arrays of rsparse::data::Sprs<f64> (data.rs:194-208)
+struct CscView {
+    i64 m = 0, n = 0;
+    const i64 *p = nullptr;
+    const i64 *i = nullptr;
+    const double *x = nullptr;  // may be null for pattern-only work
+    i64 nnz() const { return p[n]; }
+};
+
+// owning CSC
+struct Csc {
+    i64 m = 0, n = 0;
+    std::vector<i64> p, i;
+    std::vector<double> x;
+    CscView view() const { return CscView{m, n, p.data(), i.data(), x.empty() ? nullptr : x.data()}; }
+};
+
+// pattern-only CSC (orderings never look at values)
+struct Pattern {
+    i64 m = 0, n = 0;
+    std::vector<i64> p, i;
+};
+
+// rsparse::data::Symb (data.rs:1022-1038)
+struct Symbolic {
+    i64 n = 0;
+    bool has_pinv = false, has_q = false;
+    std::vector<i64> pinv;    // schol: inverse fill-reducing permutation (n)
+    std::vector<i64> q;       // sqr: column permutation as amd returns it (n+1)
+    std::vector<i64> parent;  // elimination tree
+    std::vector<i64> cp;      // column pointers of L
+    i64 m2 = 0, lnz = 0, unz = 0;
+};
+
+// rsparse::data::Nmrc for LU (data.rs:1064-1074)
+struct LuFactors {
+    Csc L, U;
+    std::vector<i64> pinv;
+};
+
+enum : int { kOk = 0, kNotPositiveDefinite = 1, kNoPivot = 2, kBadInput = -1, kDeviceError = -2 };
+
+// ---- ordering.cpp -------------------------------------------------------------------------------
+// amd (lib.rs:1292-1752): returns false for the natural ordering, else fills perm (n+1 entries).
+bool approximate_minimum_degree(const CscView &A, int order, std::vector<i64> &perm);
+
+// ---- symbolic.cpp -------------------------------------------------------------------------------
+Pattern transpose_pattern(const Pattern &A);
+// symperm, lib.rs:2369-2408; source (optional) receives, for every entry of C, the entry of A it came from
+Csc symmetric_permute_upper(const CscView &A, const i64 *pinv, std::vector<i64> *source = nullptr);
+std::vector<i64> elimination_tree(const CscView &C);             // etree(ata=false), lib.rs:2026-2071
+// schol (lib.rs:968-986): pinv, parent, cp, lnz = unz = cp[n]
+Symbolic symbolic_cholesky(const CscView &A, int order);
+// sqr, LU branch (lib.rs:1114-1119, 1134-1137): q = amd(order), lnz = unz = 4*nnz + n
+Symbolic symbolic_lu(const CscView &A, int order);
+
+// Pattern of the Cholesky factor exactly as rsparse::chol lays it out (lib.rs:295-334): Lp == cp,
+// diagonal first in each column, remaining rows strictly ascending.  Li has cp[n] entries.
+// Returns false if cp disagrees with the pattern that parent generates (a corrupt Symb).
+bool cholesky_pattern(const CscView &C_upper, const std::vector<i64> &parent, const std::vector<i64> &cp,
+                      std::vector<i64> &Li);
+
+// supernode partition of a Cholesky factor: super_start has nsuper+1 entries; consecutive columns j, j+1
+// share a supernode when parent[j] == j+1 and count[j] == count[j+1] + 1.
+std::vector<i64> fundamental_supernodes(const std::vector<i64> &parent, const std::vector<i64> &cp);
+
+// ---- lu.cpp -------------------------------------------------------------------------------------
+// lu (lib.rs:519-622) with threshold partial pivoting; q may be null (natural). Bit-exact pivot sequence,
+// L/U storage order and values (compiled with -ffp-contract=off).
+int sparse_lu(const CscView &A, const i64 *q, double tol, LuFactors &out);
+
+// ---- schedule.cpp -------------------------------------------------------------------------------
+// A triangular solve in "gather" form: unknown r is computed from earlier unknowns,
+//   x[r] = (b[r] - sum_p val[p] * x[idx[p]]) / diag[r],   p in [ptr[r], ptr[r+1])
+// processed in ascending r (lsolve, utsolve) or descending r (ltsolve, usolve).
+struct GatherForm {
+    i64 n = 0;
+    bool descending = false;
+    std::vector<i64> ptr;      // n+1
+    std::vector<int32_t> idx;  // off-diagonal column of each entry
+    std::vector<double> val;
+    std::vector<double> diag;  // n
+};
+// kind: 0 lsolve, 1 ltsolve, 2 usolve, 3 utsolve (include/rsparse_hip.h rsp_tri_kind). Returns kOk or kBadInput.
+int build_gather_form(const CscView &T, int kind, GatherForm &out);
+
+// Level schedule over "tasks".  A task is a run of consecutive unknowns (in processing order) solved
+// sequentially by one wavefront; all of its dependencies outside the run belong to tasks of lower levels.
+struct Schedule {
+    std::vector<i64> level_of_row;    // canonical level sets: 0 if no dependency, else 1 + max level of deps
+    i64 num_row_levels = 0;
+    std::vector<int32_t> task_first;  // first unknown of task t (in processing order: highest index if descending)
+    std::vector<int32_t> task_rows;   // number of unknowns in task t
+    std::vector<i64> level_ptr;       // tasks of level l are task ids [level_ptr[l], level_ptr[l+1])
+    i64 longest_task = 0;
+};
+// max_task_entries bounds the sequential work of one task (number of off-diagonal entries).
+Schedule build_schedule(const GatherForm &G, i64 max_task_entries);
+
+}  // namespace rsp

@@ -1,0 +1,253 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI, against
+   (a) the reference's golden vectors, (b) the CPU oracle on the same seeded inputs.
+Tolerances are north_star's: ||x - x_ref||inf / ||x_ref||inf <= 1e-8, relative residual <= 1e-10;
+integer structure (pattern of L) is compared exactly."""
+import numpy as np
+import pytest
+
+import rsparse_amd as rs
+from helpers import case_matrix, load_sprs, reference_cases
+from oracle import pyoracle as orc
+from rsparse_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = reference_cases()
+SOLVER = CASES["solver"]
+REL_X = 1e-8
+REL_RES = 1e-10
+
+
+def rel_inf(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def _abs_close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    assert np.all(np.abs(a[: len(b)] - b[: len(a)]) <= tol), float(np.max(np.abs(a - b)))
+
+
+# ---- (a) the reference's own tests, through the product API -----------------------------------------
+
+@pytest.mark.parametrize("name", [k for k, v in SOLVER.items() if v["call"] in ("lsolve", "ltsolve", "usolve", "utsolve")])
+def test_reference_triangular_tests(name):
+    c = SOLVER[name]
+    A = rs.Sprs.from_vec(c["dense"])
+    b = np.array(c["b"])
+    getattr(rs, c["call"])(A, b)
+    _abs_close(b, c["x"], c["tol"])
+    assert rel_inf(b, orc.trisolve(c["call"], A.as_tuple(), c["b"])) <= REL_X
+
+
+@pytest.mark.parametrize("name", [k for k, v in SOLVER.items() if v["call"] in ("cholsol", "lusol")])
+def test_reference_driver_tests(name):
+    c = SOLVER[name]
+    A = rs.Sprs.from_tuple(case_matrix(c))
+    b = np.array(c["b"], dtype=np.float64)
+    if c["check"] == "error":
+        with pytest.raises(rs.NotPositiveDefinite):
+            rs.cholsol(A, b, c["order"])
+        return
+    if c["call"] == "cholsol":
+        rs.cholsol(A, b, c["order"])
+        _, want = orc.cholsol(A.as_tuple(), c["b"], c["order"])
+    else:
+        rs.lusol(A, b, c["order"], c["lutol"])
+        _, want = orc.lusol(A.as_tuple(), c["b"], c["order"], c["lutol"])
+    if c["check"] == "x":
+        _abs_close(b, c["x"], c["tol"])
+    elif c["check"] == "x_bitwise":
+        # README.md:182. The GPU solves fuse multiply-adds, so bitwise equality is not expected; 1e-13 relative is.
+        assert rel_inf(b, np.array(c["x"])) <= 1e-13
+    elif c["check"] == "residual":
+        _abs_close(orc.gaxpy(A.as_tuple(), b, np.zeros(len(b))), c["b"], c["tol"])
+    if name != "lusol_3":  # ill-conditioned (the reference itself only asks for 0.5)
+        assert rel_inf(b, want) <= REL_X
+
+
+def test_reference_allsol_1():
+    c = SOLVER["allsol_1"]
+    A = rs.Sprs.from_tuple(case_matrix(c))
+    b1, b2 = np.array(c["b"]), np.array(c["b"])
+    rs.cholsol(A, b1, c["order_chol"])
+    rs.lusol(A, b2, c["order_lu"], c["lutol"])
+    _abs_close(b1, b2, c["tol"])
+
+
+# ---- (b) oracle parity on seeded synthetic inputs ----------------------------------------------------
+
+SPD = {
+    "lap2d_40x33": lambda: synth.laplacian_2d(40, 33),
+    "lap2d_96": lambda: synth.laplacian_2d(96),
+    "lap3d_12": lambda: synth.laplacian_3d(12),
+    "circuit_2000": lambda: synth.circuit_spd(2000),
+    "cholsol_5": lambda: load_sprs("cholsol_5.sprs"),
+    "randspd_400": lambda: synth.random_sparse(400, 0.01, seed=21, symmetric_pd=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SPD))
+@pytest.mark.parametrize("order", [0, -1])
+def test_chol_pattern_exact_values_close(name, order):
+    A = SPD[name]()
+    So = orc.schol(A, order)
+    st, Lo = orc.chol(A, So)
+    assert st == orc.OK
+    S = rs.schol(A, order)
+    N = rs.chol(A, S)
+    assert N.l.p.tolist() == Lo[2].tolist()                      # L.p == cp
+    assert N.l.i.astype(np.int64).tolist() == Lo[3].tolist()     # diagonal first, rows ascending
+    assert np.max(np.abs(N.l.x - Lo[4]) / np.maximum(np.abs(Lo[4]), 1e-300)) <= 1e-9
+    assert rel_inf(N.l.x, Lo[4]) <= 1e-12
+
+
+@pytest.mark.parametrize("name", sorted(SPD))
+def test_cholsol_vs_oracle(name):
+    A = SPD[name]()
+    n = A[0]
+    xstar = 2.0 * synth.splitmix64(1, n) - 1.0
+    b = orc.gaxpy(A, xstar, np.zeros(n))
+    st, want = orc.cholsol(A, b, 0)
+    got = b.copy()
+    rs.cholsol(A, got, 0)
+    assert rel_inf(got, want) <= REL_X
+    r = orc.gaxpy(A, got, -b)
+    assert np.linalg.norm(r) / np.linalg.norm(b) <= REL_RES
+
+
+def test_chol_upper_triangle_only_semantics():
+    """cholsol_7 (tests/solver_tests.rs:672): a non-symmetric input 'works' because only i <= j is read."""
+    A = load_sprs("cholsol_7.sprs")
+    S = rs.schol(A, 0)
+    N = rs.chol(A, S)
+    st, Lo = orc.chol(A, orc.schol(A, 0))
+    assert N.l.i.astype(np.int64).tolist() == Lo[3].tolist()
+    assert rel_inf(N.l.x, Lo[4]) <= 1e-12
+
+
+def test_chol_duplicate_entries_last_one_wins():
+    """ereach assigns x[i] = a.x[p] (lib.rs:2003): for duplicate entries the last stored one is used."""
+    m, n, p, i, x = synth.laplacian_2d(6)
+    # duplicate the first entry of every column with a different value placed BEFORE the original
+    pi, ii, xi = [0], [], []
+    for j in range(n):
+        rows, vals = i[p[j]:p[j + 1]], x[p[j]:p[j + 1]]
+        ii += [rows[0]] + rows.tolist()
+        xi += [vals[0] + 7.0] + vals.tolist()
+        pi.append(len(ii))
+    A = (m, n, np.array(pi, np.int64), np.array(ii, np.int64), np.array(xi))
+    st, Lo = orc.chol(A, orc.schol(A, -1))
+    N = rs.chol(A, rs.schol(A, -1))
+    assert st == orc.OK and rel_inf(N.l.x, Lo[4]) <= 1e-12
+
+
+def test_chol_not_positive_definite():
+    A = list(synth.laplacian_2d(8))
+    x = A[4].copy()
+    x[A[2][20]:A[2][21]] *= -1.0  # column 20 now has a negative diagonal
+    A[4] = x
+    A = tuple(A)
+    st, _ = orc.chol(A, orc.schol(A, 0))
+    assert st == orc.NOT_POSITIVE_DEFINITE
+    with pytest.raises(rs.NotPositiveDefinite):
+        rs.chol(A, rs.schol(A, 0))
+
+
+def _factors():
+    A = synth.laplacian_2d(50, 37)
+    st, L = orc.chol(A, orc.schol(A, 0))
+    B = synth.banded_unsymmetric(3000, band=30)
+    st2, f = orc.lu(B, 1, 1.0)
+    C = load_sprs("lusol_6.sprs")
+    st3, g = orc.lu(C, 1, 1e-12)
+    assert st == st2 == st3 == orc.OK
+    return {"chol_L": L, "band_L": f["L"], "band_U": f["U"], "lusol6_L": g["L"], "lusol6_U": g["U"]}
+
+
+FACTORS = None
+
+
+def factors():
+    global FACTORS
+    if FACTORS is None:
+        FACTORS = _factors()
+    return FACTORS
+
+
+KINDS = [("lsolve", "chol_L"), ("ltsolve", "chol_L"), ("lsolve", "band_L"), ("ltsolve", "band_L"), ("usolve", "band_U"),
+         ("utsolve", "band_U"), ("lsolve", "lusol6_L"), ("usolve", "lusol6_U"), ("utsolve", "lusol6_U")]
+KIND_ID = {"lsolve": 0, "ltsolve": 1, "usolve": 2, "utsolve": 3}
+
+
+@pytest.mark.parametrize("kind,fac", KINDS)
+def test_trisolve_single_rhs_vs_oracle(kind, fac):
+    T = factors()[fac]
+    n = T[0]
+    b = 2.0 * synth.splitmix64(5, n) - 1.0
+    want = orc.trisolve(kind, T, b)
+    got = b.copy()
+    getattr(rs, kind)(T, got)
+    assert rel_inf(got, want) <= REL_X
+
+
+@pytest.mark.parametrize("kind,fac", KINDS)
+@pytest.mark.parametrize("nrhs", [2, 7, 64, 130, 256])
+def test_trisolve_multi_rhs_vs_oracle(kind, fac, nrhs):
+    T = factors()[fac]
+    n = T[0]
+    B = np.asfortranarray((2.0 * synth.splitmix64(7, n * nrhs) - 1.0).reshape(nrhs, n).T)
+    want = np.stack([orc.trisolve(kind, T, B[:, r]) for r in range(nrhs)], axis=1)
+    h = rs.TriHandle(T, KIND_ID[kind])
+    X = B.copy(order="F")
+    h.solve(X)
+    assert rel_inf(X, want) <= REL_X
+    # linearity (size-independent property): solve(a*b1 + b2) == a*solve(b1) + solve(b2)
+    if nrhs >= 2:
+        y = np.asfortranarray((3.0 * B[:, 0] + B[:, 1]).reshape(n, 1))
+        h.solve(y)
+        assert rel_inf(y[:, 0], 3.0 * X[:, 0] + X[:, 1]) <= 1e-9
+
+
+def test_trisolve_device_row_major():
+    torch = pytest.importorskip("torch")
+    T = factors()["chol_L"]
+    n, nrhs = T[0], 96
+    B = (2.0 * synth.splitmix64(9, n * nrhs) - 1.0).reshape(n, nrhs)
+    want = np.stack([orc.trisolve("lsolve", T, B[:, r].copy()) for r in range(nrhs)], axis=1)
+    X = torch.tensor(B, device="cuda:0")
+    h = rs.TriHandle(T, 0)
+    h.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, nrhs, nrhs, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rel_inf(X.cpu().numpy(), want) <= REL_X
+
+
+def test_chol_handle_multi_rhs_and_refactor():
+    A = synth.laplacian_2d(64)
+    n, nrhs = A[0], 40
+    S = rs.schol(A, 0)
+    F = rs.CholHandle(A, S)
+    B = np.asfortranarray((2.0 * synth.splitmix64(3, n * nrhs) - 1.0).reshape(nrhs, n).T)
+    X = B.copy(order="F")
+    F.solve(X)
+    import scipy.sparse.linalg as spla
+    from helpers import to_scipy
+    M = to_scipy(A)
+    R = M @ X - B
+    assert np.max(np.linalg.norm(R, axis=0) / np.linalg.norm(B, axis=0)) <= REL_RES
+    st, want = orc.cholsol(A, B[:, 3].copy(), 0)
+    assert rel_inf(X[:, 3], want) <= REL_X
+    info = F.info()
+    assert info["n"] == n and info["lnz"] == S.lnz
+
+
+def test_empty_and_tiny():
+    A = rs.Sprs.from_vec([[4.0]])
+    b = np.array([2.0])
+    rs.cholsol(A, b, 0)
+    assert b[0] == 0.5
+    b = np.array([2.0])
+    rs.lusol(A, b, 1, 1.0)
+    assert b[0] == 0.5
+    b = np.array([3.0])
+    rs.lsolve(A, b)
+    assert b[0] == 0.75

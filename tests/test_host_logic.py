@@ -1,0 +1,156 @@
+"""CPU-only checks of the product's host layer (no GPU compute calls):
+   * the C-ABI library loads and exports every symbol include/rsparse_hip.h declares;
+   * integer structure computed by the product's own host code (amd, schol, lu pivoting and patterns,
+     level sets) is BIT-EXACT against the oracle and against the reference's integer pin (qr_1's q)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rsparse_amd as rs
+from helpers import case_matrix, load_sprs, reference_cases
+from oracle import pyoracle as orc
+from rsparse_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = reference_cases()
+
+
+def _matrices():
+    out = {}
+    for name in ("cholsol_1.sprs", "cholsol_2.sprs", "cholsol_5.sprs", "cholsol_7.sprs", "lusol_3.sprs", "lusol_4.sprs",
+                 "lusol_6.sprs"):
+        out[name] = load_sprs(name)
+    out["lap2d_24x17"] = synth.laplacian_2d(24, 17)
+    out["lap2d_64"] = synth.laplacian_2d(64)
+    out["lap3d_9"] = synth.laplacian_3d(9)
+    out["band_600"] = synth.banded_unsymmetric(600, band=20)
+    out["circuit_500"] = synth.circuit_spd(500)
+    out["rand_300"] = synth.random_sparse(300, 0.02, seed=11)
+    out["randspd_200"] = synth.random_sparse(200, 0.02, seed=12, symmetric_pd=True)
+    return out
+
+
+MATS = _matrices()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rsparse_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(rsp_[A-Za-z0-9_]+)\s*\(", header)))
+    L = rs.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(L._declared) == declared  # the Python mirror binds exactly the header's surface
+
+
+@pytest.mark.parametrize("name", sorted(MATS))
+@pytest.mark.parametrize("order", [-1, 0, 1, 2])
+def test_amd_bit_exact(name, order):
+    A = MATS[name]
+    want = orc.amd(A, order)
+    got = rs.amd(A, order)
+    if want is None:
+        assert got is None
+    else:
+        assert got.tolist() == want.tolist()
+
+
+def test_amd_matches_reference_pin_qr_1():
+    pin = CASES["structure"]["qr_1"]  # tests/basic_tests.rs:1282
+    assert rs.amd(load_sprs(pin["asset"]), 2).tolist() == pin["sym.q"]
+
+
+@pytest.mark.parametrize("name", [k for k in sorted(MATS) if MATS[k][0] == MATS[k][1]])
+@pytest.mark.parametrize("order", [-1, 0])
+def test_schol_bit_exact(name, order):
+    A = MATS[name]
+    want = orc.schol(A, order)
+    got = rs.schol(A, order)
+    assert (got.pinv is None) == (want["pinv"] is None)
+    if want["pinv"] is not None:
+        assert got.pinv.tolist() == want["pinv"].tolist()
+    assert got.parent.tolist() == want["parent"].tolist()
+    assert got.cp.tolist() == want["cp"].tolist()
+    assert got.lnz == got.unz == want["lnz"]
+
+
+@pytest.mark.parametrize("name", ["lusol_3.sprs", "lusol_4.sprs", "lusol_6.sprs", "cholsol_7.sprs", "band_600", "rand_300",
+                                  "circuit_500", "lap2d_24x17"])
+@pytest.mark.parametrize("order,tol", [(1, 1e-12), (1, 1.0), (-1, 1e-6), (0, 0.5)])
+def test_lu_bit_exact(name, order, tol):
+    A = MATS[name]
+    st, want = orc.lu(A, order, tol)
+    assert st == orc.OK
+    S = rs.sqr(A, order)
+    N = rs.lu(A, S, tol)
+    assert N.pinv.tolist() == want["pinv"].tolist()              # pivot sequence
+    for got, ref in ((N.l, want["L"]), (N.u, want["U"])):
+        assert got.p.tolist() == ref[2].tolist()
+        assert got.i.astype(np.int64).tolist() == ref[3].tolist()  # pattern, in storage order
+        assert np.array_equal(got.x, ref[4])                        # values, bitwise
+    q = S.q[: A[1]] if S.q is not None else np.arange(A[1])
+    assert q.tolist() == want["q"].tolist()
+
+
+def test_lu_no_pivot_error():
+    A = rs.Sprs.from_vec([[1.0, 2.0], [2.0, 4.0]])  # singular
+    with pytest.raises(rs.NoPivot):
+        rs.lu(A, rs.sqr(A, -1), 1.0)
+    st, _ = orc.lu(A.as_tuple(), -1, 1.0)
+    assert st == orc.NO_PIVOT
+
+
+def _levels_python(kind, T):
+    m, n, p, i, x = T
+    lvl = np.zeros(n, np.int64)
+    if kind in (rs.api.LSOLVE, rs.api.USOLVE):  # scatter loops of the reference: column j feeds rows i[p]
+        order = range(n) if kind == rs.api.LSOLVE else range(n - 1, -1, -1)
+        for j in order:
+            rows = i[p[j] + 1: p[j + 1]] if kind == rs.api.LSOLVE else i[p[j]: p[j + 1] - 1]
+            for r in rows:
+                lvl[r] = max(lvl[r], lvl[j] + 1)
+    else:  # gather loops: unknown j needs every x[i[p]]
+        order = range(n - 1, -1, -1) if kind == rs.api.LTSOLVE else range(n)
+        for j in order:
+            rows = i[p[j] + 1: p[j + 1]] if kind == rs.api.LTSOLVE else i[p[j]: p[j + 1] - 1]
+            for r in rows:
+                lvl[j] = max(lvl[j], lvl[r] + 1)
+    return lvl
+
+
+@pytest.mark.parametrize("name", ["cholsol_2.sprs", "cholsol_5.sprs", "lap2d_24x17", "circuit_500"])
+def test_level_sets_bit_exact_cholesky_factor(name):
+    A = MATS[name]
+    S = orc.schol(A, 0)
+    st, L = orc.chol(A, S)
+    assert st == orc.OK
+    for kind in (rs.api.LSOLVE, rs.api.LTSOLVE):
+        h = rs.TriHandle(L, kind)
+        assert h.levels().tolist() == _levels_python(kind, L).tolist()
+
+
+@pytest.mark.parametrize("name", ["lusol_4.sprs", "band_600"])
+def test_level_sets_bit_exact_lu_factors(name):
+    st, f = orc.lu(MATS[name], 1, 1.0)
+    assert st == orc.OK
+    for kind, T in ((rs.api.LSOLVE, f["L"]), (rs.api.USOLVE, f["U"]), (rs.api.UTSOLVE, f["U"]), (rs.api.LTSOLVE, f["L"])):
+        assert rs.TriHandle(T, kind).levels().tolist() == _levels_python(kind, T).tolist()
+
+
+def test_bad_input_is_reported_not_crashed():
+    # a "lower" matrix whose first entry in a column is not followed by strictly lower rows
+    T = rs.Sprs(2, 2, [0, 2, 3], [1, 0, 1], [1.0, 2.0, 3.0])
+    with pytest.raises(rs.DeviceError):
+        rs.TriHandle(T, rs.api.LSOLVE)
+    # empty column: the reference would index out of bounds (panic)
+    T = rs.Sprs(2, 2, [0, 1, 1], [0], [1.0])
+    with pytest.raises(rs.DeviceError):
+        rs.TriHandle(T, rs.api.LSOLVE)
+
+
+def test_from_vec_matches_reference_constructor():
+    c = CASES["solver"]["lsolve_1"]
+    A = rs.Sprs.from_vec(c["dense"])
+    m, n, p, i, x = case_matrix(c)
+    assert A.p.tolist() == p.tolist() and A.i.tolist() == i.tolist() and np.array_equal(A.x, x)
