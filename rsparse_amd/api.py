@@ -42,6 +42,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             raise ImportError(f"{_LIB_PATH} is missing: build it with `make -C rsparse_amd/csrc` (hipcc, gfx950)")
+        # torch bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both own the GPU.
+        # Loading torch first makes the dynamic loader resolve our DT_NEEDED against torch's copy.
+        try:
+            import torch  # noqa: F401  (plumbing only: device memory / streams / torch.distributed)
+        except ImportError:
+            pass
         L = C.CDLL(_LIB_PATH)
         vp, i64, dbl, cint = C.c_void_p, C.c_int64, C.c_double, C.c_int
         csc = C.POINTER(_Csc)

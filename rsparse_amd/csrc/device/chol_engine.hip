@@ -144,11 +144,12 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     // active slots in level order
     std::vector<int32_t> slot_panel, slot_pos, active(nslots_all, -1);
     std::vector<i64> slot_tptr(1, 0);
-    levels_.assign(nlevels_, Level{0, 0, 0, 0});
-    std::vector<int32_t> item_panel, item_block;
+    levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0});
+    std::vector<int32_t> item_panel, item_block, multi;
     for (i64 l = 0; l < nlevels_; ++l) {
         levels_[l].slot_begin = (i64)slot_panel.size();
         levels_[l].item_begin = (i64)item_panel.size();
+        multi.clear();
         for (i64 k = lv_ptr[l]; k < lv_ptr[l + 1]; ++k) {
             const i64 s = lv_panels[k];
             const i64 rows = slot_base[s + 1] - slot_base[s];
@@ -160,14 +161,21 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
                 slot_pos.push_back((int32_t)pos);
                 slot_tptr.push_back(slot_tptr.back() + tcount[slot]);
             }
-            const i64 nblk = std::max<i64>(1, (prow[s] + 63) / 64);
-            for (i64 b = 0; b < nblk; ++b) {
-                item_panel.push_back((int32_t)s);
-                item_block.push_back((int32_t)b);
-            }
+            // panels with <= 64 rows below the diagonal block are finished by one wavefront (block 0); larger ones
+            // get a diagonal-only item (block -1) now and their row blocks in a second launch
+            item_panel.push_back((int32_t)s);
+            item_block.push_back(prow[s] <= 64 ? 0 : -1);
+            if (prow[s] > 64) multi.push_back((int32_t)s);
         }
         levels_[l].slot_count = (i64)slot_panel.size() - levels_[l].slot_begin;
         levels_[l].item_count = (i64)item_panel.size() - levels_[l].item_begin;
+        levels_[l].trsm_begin = (i64)item_panel.size();
+        for (int32_t s : multi)
+            for (i64 b = 0; b < (prow[s] + 63) / 64; ++b) {
+                item_panel.push_back(s);
+                item_block.push_back((int32_t)b);
+            }
+        levels_[l].trsm_count = (i64)item_panel.size() - levels_[l].trsm_begin;
     }
     std::vector<int32_t> tuple_pair(ntuples), tuple_q(ntuples);
     {
@@ -236,7 +244,10 @@ int CholFactor::factorize(const CscView &A)
                                lv.slot_begin, lv.slot_count);
         if (lv.item_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4)), dim3(256), 0, stream, F,
-                               lv.item_begin, lv.item_count);
+                               lv.item_begin, lv.item_count, 0);
+        if (lv.trsm_count)
+            hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.trsm_count + 3) / 4)), dim3(256), 0, stream, F,
+                               lv.trsm_begin, lv.trsm_count, 1);
     }
     RSP_HIP(hipEventRecord(ev1, stream));
     RSP_HIP(hipGetLastError());

@@ -61,7 +61,8 @@ class CholFactor {
     DeviceBuffer<int32_t> d_status;  // [0] = smallest column with a non-positive pivot, or INT_MAX
     struct Level {
         i64 slot_begin, slot_count;  // update work (active slots)
-        i64 item_begin, item_count;  // factor work
+        i64 item_begin, item_count;  // factor work: whole small panels + diagonal blocks of large ones
+        i64 trsm_begin, trsm_count;  // second launch: row blocks of the large panels
     };
     std::vector<Level> levels_;
 

@@ -80,10 +80,14 @@ struct CholFactorArgs {
     int32_t *status;  // smallest column whose pivot d <= 0 (lib.rs:325)
 };
 
-// One wavefront per (panel, block of 64 rows below the diagonal block).  Every wavefront factors the w x w
-// diagonal block in its own LDS tile (w <= 32: cheaper than a second launch or a cross-workgroup hand-off);
-// block 0 writes it back.  Then lane = one row below the block:  x <- x * D^-T  (L(k,i) = x_i / L(i,i), lib.rs:310).
-__global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64_t item_begin, int64_t nitems)
+// One wavefront per work item (panel, block).  Three kinds of item, chosen on the host so that no wavefront
+// reads a diagonal block while another one overwrites it:
+//   block >= 0, trsm_only == 0 : panel with <= 64 rows below the block: factor the w x w diagonal block in LDS,
+//                                write it back, then solve this panel's rows (all in one wavefront);
+//   block == -1                : panel with more rows: factor the diagonal block and write it back, nothing else;
+//   trsm_only == 1 (next launch): load the already factored block and solve rows [64*block, 64*block + 64).
+// Row solve: lane = one row below the block,  x <- x * D^-T  (L(k,i) = x_i / L(i,i), lib.rs:310).
+__global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64_t item_begin, int64_t nitems, int trsm_only)
 {
     __shared__ double tiles[4][32][33];
     const int lane = threadIdx.x & 63;
@@ -97,22 +101,25 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     if (lane < w)
         for (int t = 0; t <= lane; ++t) D[lane][t] = A.Lx[A.Lp[c0 + t] + lane - t];
     __builtin_amdgcn_wave_barrier();
-    for (int t = 0; t < w; ++t) {
-        const double dtt = D[t][t];
-        if (dtt <= 0.0 && blk == 0 && lane == 0) atomicMin(A.status, c0 + t);
-        const double l = sqrt(dtt);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == t) D[t][t] = l;
-        if (lane > t && lane < w) D[lane][t] /= l;
-        __builtin_amdgcn_wave_barrier();
-        if (lane > t && lane < w) {
-            const double lit = D[lane][t];
-            for (int j = t + 1; j <= lane; ++j) D[lane][j] -= lit * D[j][t];
+    if (!trsm_only) {
+        for (int t = 0; t < w; ++t) {
+            const double dtt = D[t][t];
+            if (dtt <= 0.0 && lane == 0) atomicMin(A.status, c0 + t);
+            const double l = sqrt(dtt);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == t) D[t][t] = l;
+            if (lane > t && lane < w) D[lane][t] /= l;
+            __builtin_amdgcn_wave_barrier();
+            if (lane > t && lane < w) {
+                const double lit = D[lane][t];
+                for (int j = t + 1; j <= lane; ++j) D[lane][j] -= lit * D[j][t];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        if (lane < w)
+            for (int t = 0; t <= lane; ++t) A.Lx[A.Lp[c0 + t] + lane - t] = D[lane][t];
+        if (blk < 0) return;
     }
-    if (blk == 0 && lane < w)
-        for (int t = 0; t <= lane; ++t) A.Lx[A.Lp[c0 + t] + lane - t] = D[lane][t];
 
     const int rr = blk * 64 + lane;
     if (rr < r) {
