@@ -160,11 +160,13 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
     info[0] = s.n();
     info[1] = s.nnz();
     info[2] = s.num_row_levels();
-    info[3] = P.ntasks;
-    info[4] = P.nlevels;
-    info[5] = (int64_t)P.device_bytes();
+    const BlockedProgram &Bp = s.blocked_program();
+    const bool blocked = Bp.nblocks > 0;  // the programme the multi-rhs path actually ran
+    info[3] = blocked ? Bp.ntasks : P.ntasks;
+    info[4] = blocked ? Bp.nlevels : P.nlevels;
+    info[5] = (int64_t)(blocked ? Bp.device_bytes() : P.device_bytes());
     info[6] = s.algorithmic_bytes(1);
-    info[7] = P.longest_task;
+    info[7] = blocked ? Bp.inverted_rows : P.longest_task;
     return RSP_OK;
 }
 

@@ -83,6 +83,20 @@ struct TriProgram {
     }
 };
 
+// The blocked multi-right-hand-side programme (host/blocked.cpp) resident on the device.
+struct BlockedProgram {
+    i64 ntasks = 0, nlevels = 0, nblocks = 0, scratch_rows = 0, big_chains = 0, inverted_rows = 0, padded_entries = 0;
+    DeviceBuffer<i64> task_ptr, src_off, coef_off, row_off;
+    DeviceBuffer<int32_t> rc, has_tri, nsrc, rows, src_idx;
+    DeviceBuffer<double> coef;
+    std::vector<std::pair<i64, int>> levels;  // (first task, number of tasks)
+    size_t device_bytes() const
+    {
+        return task_ptr.bytes() + src_off.bytes() + coef_off.bytes() + row_off.bytes() + rc.bytes() + has_tri.bytes() +
+               nsrc.bytes() + rows.bytes() + src_idx.bytes() + coef.bytes();
+    }
+};
+
 // Analyse-once / solve-many engine for one triangular factor and one of the four solve kinds.
 class TriSolver {
    public:
@@ -99,18 +113,23 @@ class TriSolver {
     i64 num_row_levels() const { return num_row_levels_; }
     const TriProgram &multi_program() const { return multi_; }
     const TriProgram &single_program() const { return single_; }
+    const BlockedProgram &blocked_program() const { return blocked_; }
     i64 algorithmic_bytes(i64 nrhs) const { return nnz_ * 12 + (n_ + 1) * 4 + 16 * n_ * nrhs; }
 
    private:
     void build_program(i64 max_task_entries, TriProgram &P);
     void run_multi(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
+    void run_blocked(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
+    void build_blocked();
     void run_single(double *x, hipStream_t stream);
 
     i64 n_ = 0, nnz_ = 0, num_row_levels_ = 0;
     GatherForm G_;  // kept on the host so the second program can be built lazily
     std::vector<i64> level_of_row_;
     TriProgram multi_, single_;
-    bool have_multi_ = false, have_single_ = false;
+    BlockedProgram blocked_;
+    bool have_multi_ = false, have_single_ = false, have_blocked_ = false;
+    DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
 };
 

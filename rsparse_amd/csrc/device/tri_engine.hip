@@ -1,4 +1,6 @@
 // TriSolver: uploads a triangular factor in execution order and runs the level-scheduled kernels.
+#include <cstdlib>
+
 #include "engine.hpp"
 #include "solve_kernels.hip"
 
@@ -85,6 +87,53 @@ void TriSolver::run_multi(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     RSP_HIP(hipGetLastError());
 }
 
+void TriSolver::build_blocked()
+{
+    BlockProgram P = build_block_program(G_, kTaskEntriesMulti);
+    BlockedProgram &D = blocked_;
+    D.ntasks = (i64)P.task_ptr.size() - 1;
+    D.nlevels = (i64)P.level_ptr.size() - 1;
+    D.nblocks = (i64)P.rc.size();
+    D.scratch_rows = P.scratch_rows;
+    D.big_chains = P.big_chains;
+    D.inverted_rows = P.inverted_rows;
+    D.padded_entries = P.padded_entries;
+    D.levels.clear();
+    for (i64 l = 0; l < D.nlevels; ++l) D.levels.emplace_back(P.level_ptr[l], (int)(P.level_ptr[l + 1] - P.level_ptr[l]));
+    D.task_ptr.upload(P.task_ptr);
+    D.src_off.upload(P.src_off);
+    D.coef_off.upload(P.coef_off);
+    D.row_off.upload(P.row_off);
+    D.rc.upload(P.rc);
+    D.has_tri.upload(P.has_tri);
+    D.nsrc.upload(P.nsrc);
+    D.rows.upload(P.rows);
+    D.src_idx.upload(P.src_idx);
+    D.coef.upload(P.coef);
+}
+
+void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
+{
+    if (!have_blocked_) {
+        build_blocked();
+        have_blocked_ = true;
+    }
+    const BlockedProgram &P = blocked_;
+    if (P.scratch_rows) scratch_.resize((size_t)P.scratch_rows * (size_t)nrhs);
+    const dev::BlockArrays A{P.task_ptr.get(), P.rc.get(),      P.has_tri.get(), P.nsrc.get(),    P.src_off.get(),
+                             P.coef_off.get(), P.row_off.get(), P.rows.get(),    P.src_idx.get(), P.coef.get()};
+    const int wpb = 4;
+    // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
+    const int nchunks = (int)((nrhs + 63) / 64);
+    for (const auto &lv : P.levels) {
+        const i64 waves = (i64)lv.second * nchunks;
+        const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+        hipLaunchKernelGGL(dev::solve_level_blocked<1>, grid, block, 0, stream, A, lv.first, lv.second, X, ld, scratch_.get(), nrhs,
+                           (int)nrhs, nchunks);
+    }
+    RSP_HIP(hipGetLastError());
+}
+
 void TriSolver::run_single(double *x, hipStream_t stream)
 {
     if (!have_single_) {
@@ -107,8 +156,10 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
         run_single(dX, stream);
         return;
     }
+    static const bool blocked = !(getenv("RSP_TRI_BLOCKED") && getenv("RSP_TRI_BLOCKED")[0] == '0');
+    auto run = [&](double *X, i64 ldx) { blocked ? run_blocked(X, ldx, nrhs, stream) : run_multi(X, ldx, nrhs, stream); };
     if (layout == 1) {
-        run_multi(dX, ld, nrhs, stream);
+        run(dX, ld);
         return;
     }
     // column-major caller: stage through a row-major workspace (two extra passes over X)
@@ -116,7 +167,7 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
     const dim3 grid((unsigned)((n_ + 31) / 32), (unsigned)((nrhs + 31) / 32)), block(256);
     hipLaunchKernelGGL(dev::colmajor_to_rowmajor, grid, block, 0, stream, dX, ld, work_.get(), nrhs, n_, (int)nrhs,
                        (const int64_t *)nullptr, 0);
-    run_multi(work_.get(), nrhs, nrhs, stream);
+    run(work_.get(), nrhs);
     hipLaunchKernelGGL(dev::rowmajor_to_colmajor, grid, block, 0, stream, work_.get(), nrhs, dX, ld, n_, (int)nrhs,
                        (const int64_t *)nullptr, 0);
     RSP_HIP(hipGetLastError());

@@ -3,6 +3,7 @@
 // Mirrors rsparse's src/data.rs types; every routine cites the reference lines whose RESULT it must
 // reproduce.  Independent of oracle/ (which is test infrastructure and never linked here).
 #pragma once
+#include <climits>
 #include <cstdint>
 #include <vector>
 
@@ -108,5 +109,42 @@ struct Schedule {
 };
 // max_task_entries bounds the sequential work of one task (number of off-diagonal entries).
 Schedule build_schedule(const GatherForm &G, i64 max_task_entries);
+
+// ---- blocked.cpp ----------------------------------------------------------------------------------
+// The multi-right-hand-side programme.  Unknowns are grouped into BLOCKS of up to 16 unknowns that are
+// consecutive in processing order and share most of their sources (supernode rows).  A block is one unit of
+// work for a wavefront:
+//     acc[r] = init[r]  (a row of X, a scratch row, or 0)                         r < rc
+//     acc[r] -= coef[e][r] * src[e]     for every source e of the block (a row of X or a scratch row)
+//     if has_tri:  acc[r] = (acc[r] - sum_{t<r} tri[r][t] * acc[t]) / tri[r][r]   (the block's own chain)
+//     dest[r] = acc[r]
+// so every source row is loaded once and used for rc unknowns (register reuse), and the coefficients are
+// wave-uniform scalars.  Long dense chains (supernodes wider than kBigChain) are not solved sequentially:
+// their diagonal block M is inverted on the host once, and the chain becomes two sets of independent blocks,
+//     Y = X_J - L[J, ext] X_ext   (scratch)      and      X_J = M^-1 Y,
+// which removes the chain from the critical path.  Source lists longer than kChunkSources are split into
+// partial sums (scratch rows) that a small combine block adds up.
+struct BlockProgram {
+    static constexpr int32_t kNone = INT32_MIN;
+    // per block
+    std::vector<int32_t> rc;         // class size: 1, 2, 4, 8 or 16 (rows padded with kNone)
+    std::vector<int32_t> has_tri;    // 1: in-block triangular solve with the tri coefficients
+    std::vector<int32_t> nsrc;       // number of sources
+    std::vector<i64> src_off;        // first source in src_idx
+    std::vector<i64> coef_off;       // first coefficient: nsrc*rc source coefficients, then rc*rc tri coefficients
+    std::vector<i64> row_off;        // into rows: rc destination ids, then rc init ids
+    // pools
+    std::vector<int32_t> rows;       // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
+    std::vector<int32_t> src_idx;    // same encoding
+    std::vector<double> coef;
+    // schedule
+    std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
+    std::vector<i64> level_ptr;      // tasks of level l
+    i64 scratch_rows = 0;
+    i64 big_chains = 0, inverted_rows = 0, padded_entries = 0;
+};
+constexpr i64 kBigChain = 32;        // chains longer than this are replaced by their inverse
+constexpr i64 kChunkSources = 256;   // sources per partial block
+BlockProgram build_block_program(const GatherForm &G, i64 max_task_entries);
 
 }  // namespace rsp
