@@ -86,15 +86,12 @@ struct TriProgram {
 // The blocked multi-right-hand-side programme (host/blocked.cpp) resident on the device.
 struct BlockedProgram {
     i64 ntasks = 0, nlevels = 0, nblocks = 0, scratch_rows = 0, big_chains = 0, inverted_rows = 0, padded_entries = 0;
-    DeviceBuffer<i64> task_ptr, src_off, coef_off, row_off;
-    DeviceBuffer<int32_t> rc, has_tri, nsrc, rows, src_idx;
+    DeviceBuffer<i64> task_ptr;
+    DeviceBuffer<BlockHeader> hdr;
+    DeviceBuffer<int32_t> src_idx;
     DeviceBuffer<double> coef;
     std::vector<std::pair<i64, int>> levels;  // (first task, number of tasks)
-    size_t device_bytes() const
-    {
-        return task_ptr.bytes() + src_off.bytes() + coef_off.bytes() + row_off.bytes() + rc.bytes() + has_tri.bytes() +
-               nsrc.bytes() + rows.bytes() + src_idx.bytes() + coef.bytes();
-    }
+    size_t device_bytes() const { return task_ptr.bytes() + hdr.bytes() + src_idx.bytes() + coef.bytes(); }
 };
 
 // Analyse-once / solve-many engine for one triangular factor and one of the four solve kinds.

@@ -178,226 +178,3 @@ __global__ __launch_bounds__(256) void permute_rows(const double *__restrict__ i
 }  // namespace dev
 }  // namespace rsp
 
-// ==== blocked multi-right-hand-side programme (host/blocked.cpp) ===========================================
-namespace rsp {
-namespace dev {
-
-struct BlockArrays {
-    const int64_t *task_ptr;  // blocks of task t (tasks sorted by level)
-    const int32_t *rc;        // per block: class size 1/2/4/8/16
-    const int32_t *has_tri;
-    const int32_t *nsrc;
-    const int64_t *src_off, *coef_off, *row_off;
-    const int32_t *rows;      // rc dest ids then rc init ids; id >= 0 row of X, id < 0 scratch row ~id, INT32_MIN none
-    const int32_t *src_idx;
-    const double *coef;
-};
-
-#define RSP_NONE INT32_MIN
-
-template <int V>
-__device__ __forceinline__ const double *row_ptr(int32_t id, const double *X, int64_t ldx, const double *S, int64_t lds)
-{
-    return id >= 0 ? X + (int64_t)id * ldx : S + (int64_t)(~id) * lds;
-}
-
-// One block: RC unknowns x V right-hand sides per lane, all in registers.
-template <int RC, int V>
-__device__ __forceinline__ void run_block(const BlockArrays &B, int64_t b, double *X, int64_t ldx, double *S, int64_t lds, int col0)
-{
-    const int32_t *rows = B.rows + B.row_off[b];
-    const int ns = B.nsrc[b];
-    const int32_t *sidx = B.src_idx + B.src_off[b];
-    const double *cf = B.coef + B.coef_off[b];
-    double acc[RC][V];
-#pragma unroll
-    for (int r = 0; r < RC; ++r) {
-        const int32_t id = rows[RC + r];
-        if (id != RSP_NONE) {
-            const double *p = row_ptr<V>(id, X, ldx, S, lds) + col0;
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[r][v] = p[v];
-        } else {
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[r][v] = 0.0;
-        }
-    }
-    // U source rows in flight per wavefront: all ids (scalar), then all row loads, then the multiply-adds
-    constexpr int U = (RC * V >= 32) ? 4 : 8;
-    int e = 0;
-    for (; e + U <= ns; e += U) {
-        double x[U][V];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double *p = row_ptr<V>(sidx[e + u], X, ldx, S, lds) + col0;
-#pragma unroll
-            for (int v = 0; v < V; ++v) x[u][v] = p[v];
-        }
-        const double *c0 = cf + (int64_t)e * RC;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int r = 0; r < RC; ++r) {
-                const double a = c0[u * RC + r];
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc[r][v] -= a * x[u][v];
-            }
-        }
-    }
-    for (; e < ns; ++e) {
-        const double *p0 = row_ptr<V>(sidx[e], X, ldx, S, lds) + col0;
-        const double *c0 = cf + (int64_t)e * RC;
-        double x0[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) x0[v] = p0[v];
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            const double a0 = c0[r];
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[r][v] -= a0 * x0[v];
-        }
-    }
-    if (B.has_tri[b]) {
-        const double *tri = cf + (int64_t)ns * RC;
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-#pragma unroll
-            for (int t = 0; t < r; ++t) {
-                const double a = tri[r * RC + t];
-#pragma unroll
-                for (int v = 0; v < V; ++v) acc[r][v] -= a * acc[t][v];
-            }
-            const double d = tri[r * RC + r];
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[r][v] /= d;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < RC; ++r) {
-        const int32_t id = rows[r];
-        if (id != RSP_NONE) {
-            double *p = const_cast<double *>(row_ptr<V>(id, X, ldx, S, lds)) + col0;
-#pragma unroll
-            for (int v = 0; v < V; ++v) p[v] = acc[r][v];
-        }
-    }
-}
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// 16-unknown block on the matrix cores.  acc (16 unknowns x 64*V right-hand sides) lives in the C/D layout of
-// v_mfma_f64_16x16x4_f64: lane (g = lane >> 4, j = lane & 15), register s  <->  unknown 4*s + g, columns
-// col0 + j*NT + nt (NT = 4*V tiles, so every lane owns NT CONSECUTIVE doubles of a row: wide loads/stores).
-// One K-step consumes 4 sources: A = coefficients (lane (g, i): coef[source 4k+g][unknown i], a fully coalesced
-// 512-byte read of the coefficient stream), B = the 4 gathered source rows (lane (g, j): NT doubles of source
-// 4k+g).  No scalar loads and no cross-lane traffic; the in-block triangular solve is 4 more K-steps with
-// A = inverse of the block's 16 x 16 triangle and B = acc itself (C/D register s IS the B operand of K-step s).
-template <int V>
-__device__ __forceinline__ void run_block_mfma(const BlockArrays &B, int64_t b, double *X, int64_t ldx, double *S, int64_t lds,
-                                               int col0, int nrhs, int lane)
-{
-    constexpr int NT = 4 * V;
-    const int g = lane >> 4, j = lane & 15;
-    const int cb = col0 + j * NT;  // first column of this lane
-    const bool full = cb + NT <= nrhs;
-    const int32_t *rows = B.rows + B.row_off[b];
-    const int ns = B.nsrc[b];  // padded to a multiple of 4 by the host
-    const int32_t *sidx = B.src_idx + B.src_off[b];
-    const double *cf = B.coef + B.coef_off[b];
-    f64x4 acc[NT];
-    // init: register s <- row (4s + g)
-#pragma unroll
-    for (int sidx4 = 0; sidx4 < 4; ++sidx4) {
-        const int32_t id = rows[16 + 4 * sidx4 + g];
-        double v[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) v[nt] = 0.0;
-        if (id != RSP_NONE) {
-            const double *p = row_ptr<V>(id, X, ldx, S, lds) + cb;
-            if (full) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) v[nt] = p[nt];
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    if (cb + nt < nrhs) v[nt] = p[nt];
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt][sidx4] = v[nt];
-    }
-#pragma unroll 2
-    for (int e = 0; e < ns; e += 4) {
-        const int32_t id = sidx[e + g];
-        const double a = -cf[(int64_t)e * 16 + lane];
-        const double *p = row_ptr<V>(id, X, ldx, S, lds) + cb;
-        double xb[NT];
-        if (full) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) xb[nt] = p[nt];
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) xb[nt] = (cb + nt < nrhs) ? p[nt] : 0.0;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[nt], acc[nt], 0, 0, 0);
-    }
-    if (B.has_tri[b]) {
-        const double *tinv = cf + (int64_t)ns * 16;  // 4 x 64 doubles in A-operand order
-        double a4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = tinv[k * 64 + lane];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f64x4 r = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) r = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[k], acc[nt][k], r, 0, 0, 0);
-            acc[nt] = r;
-        }
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const int32_t id = rows[4 * s4 + g];
-        if (id != RSP_NONE) {
-            double *p = const_cast<double *>(row_ptr<V>(id, X, ldx, S, lds)) + cb;
-            if (full) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) p[nt] = acc[nt][s4];
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    if (cb + nt < nrhs) p[nt] = acc[nt][s4];
-            }
-        }
-    }
-}
-
-// one wavefront per (task, block of 64*V columns); blocks of a task run in order
-template <int V>
-__global__ __launch_bounds__(256, 4) void solve_level_blocked(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx,
-                                                            double *S, int64_t lds, int nrhs, int nchunks)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const int t = wave / nchunks;
-    if (t >= ntasks) return;
-    const int chunk = wave - t * nchunks;
-    const int cw = chunk * 64 * V;          // first column of this wavefront
-    const int col0 = cw + lane * V;         // first column of this lane in the vector (rc <= 4) path
-    const int64_t bend = B.task_ptr[task_begin + t + 1];
-    for (int64_t b = B.task_ptr[task_begin + t]; b < bend; ++b) {
-        const int rc = B.rc[b];
-        if (rc == 16) {
-            run_block_mfma<V>(B, b, X, ldx, S, lds, cw, nrhs, lane);  // every lane takes part (EXEC all ones)
-        } else if (col0 < nrhs) {
-            switch (rc) {
-                case 1: run_block<1, V>(B, b, X, ldx, S, lds, col0); break;
-                case 2: run_block<2, V>(B, b, X, ldx, S, lds, col0); break;
-                default: run_block<4, V>(B, b, X, ldx, S, lds, col0); break;
-            }
-        }
-    }
-}
-
-}  // namespace dev
-}  // namespace rsp

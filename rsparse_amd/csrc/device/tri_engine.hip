@@ -3,6 +3,7 @@
 
 #include "engine.hpp"
 #include "solve_kernels.hip"
+#include "blocked_kernels.hip"
 
 namespace rsp {
 
@@ -93,7 +94,7 @@ void TriSolver::build_blocked()
     BlockedProgram &D = blocked_;
     D.ntasks = (i64)P.task_ptr.size() - 1;
     D.nlevels = (i64)P.level_ptr.size() - 1;
-    D.nblocks = (i64)P.rc.size();
+    D.nblocks = (i64)P.hdr.size();
     D.scratch_rows = P.scratch_rows;
     D.big_chains = P.big_chains;
     D.inverted_rows = P.inverted_rows;
@@ -101,13 +102,8 @@ void TriSolver::build_blocked()
     D.levels.clear();
     for (i64 l = 0; l < D.nlevels; ++l) D.levels.emplace_back(P.level_ptr[l], (int)(P.level_ptr[l + 1] - P.level_ptr[l]));
     D.task_ptr.upload(P.task_ptr);
-    D.src_off.upload(P.src_off);
-    D.coef_off.upload(P.coef_off);
-    D.row_off.upload(P.row_off);
-    D.rc.upload(P.rc);
-    D.has_tri.upload(P.has_tri);
-    D.nsrc.upload(P.nsrc);
-    D.rows.upload(P.rows);
+    D.hdr.upload(P.hdr);
+    // the kernel fetches ids and coefficients a wavefront at a time (clamped lane offsets), never past these ends
     D.src_idx.upload(P.src_idx);
     D.coef.upload(P.coef);
 }
@@ -120,15 +116,14 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     }
     const BlockedProgram &P = blocked_;
     if (P.scratch_rows) scratch_.resize((size_t)P.scratch_rows * (size_t)nrhs);
-    const dev::BlockArrays A{P.task_ptr.get(), P.rc.get(),      P.has_tri.get(), P.nsrc.get(),    P.src_off.get(),
-                             P.coef_off.get(), P.row_off.get(), P.rows.get(),    P.src_idx.get(), P.coef.get()};
+    const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get()};
     const int wpb = 4;
     // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
     const int nchunks = (int)((nrhs + 63) / 64);
     for (const auto &lv : P.levels) {
         const i64 waves = (i64)lv.second * nchunks;
         const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-        hipLaunchKernelGGL(dev::solve_level_blocked<1>, grid, block, 0, stream, A, lv.first, lv.second, X, ld, scratch_.get(), nrhs,
+        hipLaunchKernelGGL(dev::solve_level_blocked, grid, block, 0, stream, A, lv.first, lv.second, X, ld, scratch_.get(), nrhs,
                            (int)nrhs, nchunks);
     }
     RSP_HIP(hipGetLastError());

@@ -75,14 +75,10 @@ class Builder {
     {
         const int rc = class_of(rows);
         std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
-        const i64 b = (i64)P_.rc.size();
-        P_.rc.push_back(rc);
-        P_.has_tri.push_back(tri ? 1 : 0);
-        P_.src_off.push_back((i64)P_.src_idx.size());
-        P_.coef_off.push_back((i64)P_.coef.size());
-        P_.row_off.push_back((i64)P_.rows.size());
-        for (int r = 0; r < rc; ++r) P_.rows.push_back(r < rows ? dest[r] : kNone);
-        for (int r = 0; r < rc; ++r) P_.rows.push_back(r < rows ? init[r] : kNone);
+        const i64 b = (i64)P_.hdr.size();
+        BlockHeader h{rc, 0, tri ? 1 : 0, 0, (i64)P_.src_idx.size(), (i64)P_.coef.size()};
+        for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? dest[r] : kNone);
+        for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? init[r] : kNone);
         i64 ns = 0;
         for (size_t k = 0; k < src.size();) {
             const int32_t pos = src[k].pos;
@@ -92,12 +88,13 @@ class Builder {
             for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] = src[k].val;
             ++ns;
         }
-        if (rc == 16)  // the matrix-core path consumes sources four at a time: pad with zero coefficients
-            for (; ns % 4 != 0; ++ns) {
+        if (rc == 16)  // the matrix-core path consumes sources sixteen at a time: pad with zero coefficients
+            for (; ns % 16 != 0; ++ns) {
                 P_.src_idx.push_back(P_.src_idx.back());
                 P_.coef.resize(P_.coef.size() + rc, 0.0);
             }
-        P_.nsrc.push_back((int32_t)ns);
+        h.nsrc = (int32_t)ns;
+        P_.hdr.push_back(h);
         if (tri && rc < 16) {
             const size_t base = P_.coef.size();
             P_.coef.resize(base + (size_t)rc * rc, 0.0);
@@ -228,7 +225,7 @@ class Builder {
             if (cur_task_ >= 0 && chained) need = std::max<i64>(need, task_level_[cur_task_] + 1);
             level = need;
             cur_task_ = (i64)task_level_.size();
-            task_first_blk_.push_back((i64)P_.rc.size());
+            task_first_blk_.push_back((i64)P_.hdr.size());
             task_level_.push_back((int32_t)level);
             task_nblk_.push_back(1);
             cur_work_ = work;
@@ -376,22 +373,16 @@ class Builder {
         std::vector<i64> fill(P_.level_ptr.begin(), P_.level_ptr.end() - 1), order(ntasks);
         for (i64 t = 0; t < ntasks; ++t) order[fill[task_level_[t]]++] = t;
         // permute the per-block arrays into task order
-        const i64 nblk = (i64)P_.rc.size();
-        std::vector<int32_t> rc(nblk), tri(nblk), ns(nblk);
-        std::vector<i64> so(nblk), co(nblk), ro(nblk);
+        std::vector<BlockHeader> hdr(P_.hdr.size());
         P_.task_ptr.assign(ntasks + 1, 0);
         i64 at = 0;
         for (i64 k = 0; k < ntasks; ++k) {
             const i64 t = order[k];
             P_.task_ptr[k] = at;
-            for (i64 b = task_first_blk_[t]; b < task_first_blk_[t] + task_nblk_[t]; ++b, ++at) {
-                rc[at] = P_.rc[b]; tri[at] = P_.has_tri[b]; ns[at] = P_.nsrc[b];
-                so[at] = P_.src_off[b]; co[at] = P_.coef_off[b]; ro[at] = P_.row_off[b];
-            }
+            for (i64 b = task_first_blk_[t]; b < task_first_blk_[t] + task_nblk_[t]; ++b, ++at) hdr[at] = P_.hdr[b];
         }
         P_.task_ptr[ntasks] = at;
-        P_.rc.swap(rc); P_.has_tri.swap(tri); P_.nsrc.swap(ns);
-        P_.src_off.swap(so); P_.coef_off.swap(co); P_.row_off.swap(ro);
+        P_.hdr.swap(hdr);
     }
 
     const GatherForm &G_;

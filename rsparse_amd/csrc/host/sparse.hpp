@@ -124,18 +124,19 @@ Schedule build_schedule(const GatherForm &G, i64 max_task_entries);
 //     Y = X_J - L[J, ext] X_ext   (scratch)      and      X_J = M^-1 Y,
 // which removes the chain from the critical path.  Source lists longer than kChunkSources are split into
 // partial sums (scratch rows) that a small combine block adds up.
+struct BlockHeader {   // 32 bytes: the device reads it with one scalar load
+    int32_t rc;        // class size: 1, 2, 4 (vector path) or 16 (matrix-core path); rows padded with kNone
+    int32_t nsrc;      // number of sources; rc == 16: padded to a multiple of 16 with zero coefficients
+    int32_t has_tri;   // 1: in-block triangular solve with the tri coefficients
+    int32_t pad;
+    i64 src_off;       // into src_idx: [rc destination ids][rc init ids][nsrc source ids]
+    i64 coef_off;      // into coef: nsrc*rc source coefficients, then the triangle (rc*rc, or 256 for rc == 16)
+};
 struct BlockProgram {
     static constexpr int32_t kNone = INT32_MIN;
-    // per block
-    std::vector<int32_t> rc;         // class size: 1, 2, 4, 8 or 16 (rows padded with kNone)
-    std::vector<int32_t> has_tri;    // 1: in-block triangular solve with the tri coefficients
-    std::vector<int32_t> nsrc;       // number of sources
-    std::vector<i64> src_off;        // first source in src_idx
-    std::vector<i64> coef_off;       // first coefficient: nsrc*rc source coefficients, then rc*rc tri coefficients
-    std::vector<i64> row_off;        // into rows: rc destination ids, then rc init ids
+    std::vector<BlockHeader> hdr;    // per block
     // pools
-    std::vector<int32_t> rows;       // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
-    std::vector<int32_t> src_idx;    // same encoding
+    std::vector<int32_t> src_idx;    // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
     std::vector<double> coef;
     // schedule
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
