@@ -110,27 +110,14 @@ def main():
         extras["supernodes"] = fi["supernodes"]
         del F
         Lp, Li, Lx = L.p, L.i.astype(np.int64), L.x
-        meta = torch.tensor([len(Lx)], dtype=torch.int64, device=dev)
-    else:
-        meta = torch.zeros(1, dtype=torch.int64, device=dev)
 
     # ---- the factor travels to the other GPUs once (RCCL broadcast over xGMI), untimed -------------------------
     if world > 1:
+        from rsparse_amd import sharding
         t0 = time.time()
-        dist.broadcast(meta, 0)
-        lnz = int(meta.item())
-        if rank == 0:
-            tp, ti, tx = (torch.tensor(a, device=dev) for a in (Lp, Li, Lx))
-        else:
-            tp = torch.empty(n + 1, dtype=torch.int64, device=dev)
-            ti = torch.empty(lnz, dtype=torch.int64, device=dev)
-            tx = torch.empty(lnz, dtype=torch.float64, device=dev)
-        for t in (tp, ti, tx):
-            dist.broadcast(t, 0)
+        Lall = sharding.broadcast_factor((n, n, Lp, Li, Lx) if rank == 0 else None, 0, dev, dist)
+        _, _, Lp, Li, Lx = Lall
         torch.cuda.synchronize()
-        if rank != 0:
-            Lp, Li, Lx = tp.cpu().numpy(), ti.cpu().numpy(), tx.cpu().numpy()
-        del tp, ti, tx
         setup["broadcast_s"] = time.time() - t0
     lnz = len(Lx)
 
@@ -223,7 +210,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "solve_level_multi (all level launches of one lsolve+ltsolve step)",
+                "kernel": "solve_level_blocked (all level launches of one lsolve+ltsolve step)",
             },
             "setup": setup,
             "check": check,

@@ -1,0 +1,78 @@
+"""Sharding of the solve path across the GPUs of one node (one process per GPU, torch.distributed).
+
+The path shards by INDEPENDENT right-hand-side columns (or independent systems of a batch): every rank holds the whole
+factor and owns a contiguous block of columns, so the solve itself needs no collective.  RCCL (backend "nccl") or gloo
+is used for exactly two things: broadcasting the factor arrays once from the rank that factored, and gathering the
+solution blocks on one rank when the caller wants them there.  No counterpart in the reference (single-threaded CPU).
+"""
+import numpy as np
+
+
+def column_block(total, world, rank):
+    """Contiguous block [start, start + count) of `total` columns (or systems) owned by `rank`; sizes differ by <= 1."""
+    if world <= 0 or not (0 <= rank < world) or total < 0:
+        raise ValueError("bad partition request")
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def broadcast_factor(L, src, device, dist):
+    """L = (m, n, p, i, x) on rank `src` (ignored elsewhere) -> the same tuple on every rank.
+
+    int64 / int64 / float64 arrays travel as three broadcasts (p, i, x) after a 3-word header; on the nccl backend the
+    staging tensors live on `device` so the transfer goes GPU to GPU over xGMI."""
+    import torch
+    rank = dist.get_rank()
+    hdr = torch.zeros(3, dtype=torch.int64, device=device)
+    if rank == src:
+        m, n, p, i, x = L
+        hdr = torch.tensor([m, n, len(x)], dtype=torch.int64, device=device)
+    dist.broadcast(hdr, src)
+    m, n, nz = (int(v) for v in hdr.cpu())
+    if rank == src:
+        tp = torch.as_tensor(np.ascontiguousarray(p, np.int64), device=device)
+        ti = torch.as_tensor(np.ascontiguousarray(i, np.int64), device=device)
+        tx = torch.as_tensor(np.ascontiguousarray(x, np.float64), device=device)
+    else:
+        tp = torch.empty(n + 1, dtype=torch.int64, device=device)
+        ti = torch.empty(nz, dtype=torch.int64, device=device)
+        tx = torch.empty(nz, dtype=torch.float64, device=device)
+    for t in (tp, ti, tx):
+        dist.broadcast(t, src)
+    return (m, n, tp.cpu().numpy(), ti.cpu().numpy(), tx.cpu().numpy())
+
+
+def gather_columns(local, total, dst, device, dist):
+    """local: (n, count) array holding this rank's column block -> (n, total) array on rank `dst`, None elsewhere."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = local.shape[0]
+    counts = [column_block(total, world, r)[1] for r in range(world)]
+    width = max(counts) if counts else 0
+    pad = torch.zeros((width, n), dtype=torch.float64, device=device)  # column blocks travel as contiguous rows
+    pad[: local.shape[1]] = torch.as_tensor(np.ascontiguousarray(local.T), device=device)
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    if dist.get_backend() == "nccl":  # no gather primitive on every RCCL build: all_gather, non-roots drop the result
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+    else:
+        dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = np.empty((n, total), dtype=np.float64, order="F")
+    for r in range(world):
+        s, c = column_block(total, world, r)
+        out[:, s:s + c] = bufs[r][:c].cpu().numpy().T
+    return out
+
+
+def solve_sharded(solve_block, B, dst, device, dist):
+    """Solve all columns of B (n x nrhs, present on every rank) with `solve_block(block) -> block`, each rank taking
+    its own column block; the assembled solution is returned on rank `dst`."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    s, c = column_block(B.shape[1], world, rank)
+    mine = np.asfortranarray(B[:, s:s + c].copy())
+    if c:
+        mine = solve_block(mine)
+    return gather_columns(mine, B.shape[1], dst, device, dist)
