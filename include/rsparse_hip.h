@@ -80,6 +80,14 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info);
 /* integer schedule, for bit-exact comparison with the host oracle: level_of_row[n] */
 int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row);
 void rsp_tri_free(rsp_tri *h);
+/* Host-only validator of the multi-right-hand-side programme built for T (debug aid; no reference counterpart, needs
+ * no GPU and solves nothing for the caller): replays the programme on one synthetic right-hand side with every index
+ * bounds-checked and every read checked against the level that produces it.
+ * report[0..7] = bad indices, order violations, unknowns not written exactly once, levels, block tasks, clusters,
+ *                unknowns inside clusters, kernel launches per sweep;  *max_rel_error = against sequential substitution.
+ * task_blocks / cluster_slots <= 0 select the library defaults. */
+int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
+                             double *max_rel_error);
 
 /* ---- symbolic analysis (host CPU) -------------------------------------------------------------
  * rsparse::schol (src/lib.rs:968-986) and the LU branch of rsparse::sqr (src/lib.rs:1114-1119,1134-1137).

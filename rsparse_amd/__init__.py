@@ -17,6 +17,7 @@ from .api import (  # noqa: F401
     Sprs,
     Symb,
     TriHandle,
+    validate_program,
     amd,
     chol,
     cholsol,

@@ -65,6 +65,7 @@ def lib():
             "rsp_tri_info": (cint, [vp, vp]),
             "rsp_tri_levels": (cint, [vp, vp]),
             "rsp_tri_free": (None, [vp]),
+            "rsp_tri_validate_program": (cint, [csc, cint, i64, cint, vp, vp]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_sqr_lu": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_symb_from_parts": (cint, [i64, vp, vp, vp, vp, C.POINTER(vp)]),
@@ -326,6 +327,18 @@ def lusol(a, b, order, tol):
     a = _as_sprs(a)
     assert b.dtype == np.float64 and b.flags.c_contiguous
     _check(lib().rsp_lusol_f64(C.byref(a._view()), b.ctypes.data, order, tol))
+
+
+def validate_program(t, kind, task_blocks=0, cluster_slots=0):
+    """Host-only check of the multi-RHS programme built for `t` (rsp_tri_validate_program); no GPU needed."""
+    t = _as_sprs(t)
+    rep = np.zeros(8, np.int64)
+    err = C.c_double(0.0)
+    _check(lib().rsp_tri_validate_program(C.byref(t._view()), kind, task_blocks, cluster_slots, rep.ctypes.data, C.byref(err)))
+    keys = ("bad_index", "order_violations", "unwritten", "levels", "tasks", "clusters", "cluster_rows", "launches")
+    d = dict(zip(keys, rep.tolist()))
+    d["max_rel_error"] = err.value
+    return d
 
 
 class TriHandle:

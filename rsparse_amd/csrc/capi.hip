@@ -163,7 +163,7 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
     const BlockedProgram &Bp = s.blocked_program();
     const bool blocked = Bp.nblocks > 0;  // the programme the multi-rhs path actually ran
     info[3] = blocked ? Bp.ntasks : P.ntasks;
-    info[4] = blocked ? Bp.nlevels : P.nlevels;
+    info[4] = blocked ? Bp.launches : P.nlevels;
     info[5] = (int64_t)(blocked ? Bp.device_bytes() : P.device_bytes());
     info[6] = s.algorithmic_bytes(1);
     info[7] = blocked ? Bp.inverted_rows : P.longest_task;
@@ -179,6 +179,32 @@ int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row)
 }
 
 void rsp_tri_free(rsp_tri *h) { delete h; }
+
+int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
+                             double *max_rel_error)
+{
+    if (!sane(T) || !report || !max_rel_error) return RSP_BAD_INPUT;
+    return guarded([&] {
+        GatherForm G;
+        if (int st = build_gather_form(view_of(T), kind, G)) return st;
+        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks,
+                                                   cluster_slots > 0 ? cluster_slots : kClusterSlots);
+        const ProgramReport R = check_block_program(G, P);
+        report[0] = R.bad_index;
+        report[1] = R.order_violations;
+        report[2] = R.unwritten;
+        report[3] = (int64_t)P.level_ptr.size() - 1;
+        report[4] = (int64_t)P.task_ptr.size() - 1;
+        report[5] = (int64_t)P.clusters.size();
+        report[6] = P.cluster_rows;
+        int64_t launches = 0;
+        for (size_t l = 0; l + 1 < P.level_ptr.size(); ++l)
+            launches += (P.level_ptr[l + 1] > P.level_ptr[l]) + (P.cluster_level_ptr[l + 1] > P.cluster_level_ptr[l]);
+        report[7] = launches;
+        *max_rel_error = R.max_rel_error;
+        return (int)RSP_OK;
+    });
+}
 
 // ---- symbolic -----------------------------------------------------------------------------------
 

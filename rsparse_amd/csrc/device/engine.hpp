@@ -86,12 +86,27 @@ struct TriProgram {
 // The blocked multi-right-hand-side programme (host/blocked.cpp) resident on the device.
 struct BlockedProgram {
     i64 ntasks = 0, nlevels = 0, nblocks = 0, scratch_rows = 0, big_chains = 0, inverted_rows = 0, padded_entries = 0;
+    i64 nclusters = 0, cluster_rows = 0, cluster_entries = 0, launches = 0;
+    int cluster_slots = 0;
     DeviceBuffer<i64> task_ptr;
     DeviceBuffer<BlockHeader> hdr;
     DeviceBuffer<int32_t> src_idx;
     DeviceBuffer<double> coef;
-    std::vector<std::pair<i64, int>> levels;  // (first task, number of tasks)
-    size_t device_bytes() const { return task_ptr.bytes() + hdr.bytes() + src_idx.bytes() + coef.bytes(); }
+    DeviceBuffer<ClusterHeader> clusters;
+    DeviceBuffer<int32_t> cluster_ids;
+    DeviceBuffer<GroupRec> groups;
+    struct Level {
+        i64 task_begin;
+        int ntasks;
+        i64 cluster_begin;
+        int nclusters;
+    };
+    std::vector<Level> levels;
+    size_t device_bytes() const
+    {
+        return task_ptr.bytes() + hdr.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
+               groups.bytes();
+    }
 };
 
 // Analyse-once / solve-many engine for one triangular factor and one of the four solve kinds.
@@ -131,7 +146,7 @@ class TriSolver {
 };
 
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)
-constexpr i64 kTaskEntriesMulti = 2048;
+constexpr i64 kTaskEntriesMulti = 2048;   // unblocked fallback programme
 constexpr i64 kTaskEntriesSingle = 512;
 
 }  // namespace rsp

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "solve_kernels.hip"
 #include "blocked_kernels.hip"
+#include "cluster_kernels.hip"
 
 namespace rsp {
 
@@ -88,9 +89,15 @@ void TriSolver::run_multi(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     RSP_HIP(hipGetLastError());
 }
 
+static i64 env_or(const char *name, i64 fallback)
+{
+    const char *v = getenv(name);
+    return v && *v ? atol(v) : fallback;
+}
+
 void TriSolver::build_blocked()
 {
-    BlockProgram P = build_block_program(G_, kTaskEntriesMulti);
+    BlockProgram P = build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots));
     BlockedProgram &D = blocked_;
     D.ntasks = (i64)P.task_ptr.size() - 1;
     D.nlevels = (i64)P.level_ptr.size() - 1;
@@ -99,13 +106,29 @@ void TriSolver::build_blocked()
     D.big_chains = P.big_chains;
     D.inverted_rows = P.inverted_rows;
     D.padded_entries = P.padded_entries;
+    D.nclusters = (i64)P.clusters.size();
+    D.cluster_rows = P.cluster_rows;
+    D.cluster_entries = P.cluster_entries;
+    D.cluster_slots = P.cluster_slots;
     D.levels.clear();
-    for (i64 l = 0; l < D.nlevels; ++l) D.levels.emplace_back(P.level_ptr[l], (int)(P.level_ptr[l + 1] - P.level_ptr[l]));
+    D.launches = 0;
+    for (i64 l = 0; l < D.nlevels; ++l) {
+        BlockedProgram::Level lv{P.level_ptr[l], (int)(P.level_ptr[l + 1] - P.level_ptr[l]), P.cluster_level_ptr[l],
+                                 (int)(P.cluster_level_ptr[l + 1] - P.cluster_level_ptr[l])};
+        D.launches += (lv.ntasks > 0) + (lv.nclusters > 0);
+        D.levels.push_back(lv);
+    }
     D.task_ptr.upload(P.task_ptr);
     D.hdr.upload(P.hdr);
-    // the kernel fetches ids and coefficients a wavefront at a time (clamped lane offsets), never past these ends
+    // the kernels fetch ids and coefficients a wavefront at a time (clamped lane offsets), never past these ends
     D.src_idx.upload(P.src_idx);
     D.coef.upload(P.coef);
+    D.clusters.upload(P.clusters);
+    D.cluster_ids.upload(P.cluster_ids);
+    D.groups.upload(P.groups);
+    if ((size_t)D.cluster_slots * 512 + 1024 > 64 * 1024)
+        RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    D.cluster_slots * 512 + 1024));
 }
 
 void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
@@ -117,14 +140,20 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     const BlockedProgram &P = blocked_;
     if (P.scratch_rows) scratch_.resize((size_t)P.scratch_rows * (size_t)nrhs);
     const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get()};
+    const dev::ClusterArrays C{P.clusters.get(), P.cluster_ids.get(), P.groups.get()};
     const int wpb = 4;
     // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
     const int nchunks = (int)((nrhs + 63) / 64);
     for (const auto &lv : P.levels) {
-        const i64 waves = (i64)lv.second * nchunks;
-        const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-        hipLaunchKernelGGL(dev::solve_level_blocked, grid, block, 0, stream, A, lv.first, lv.second, X, ld, scratch_.get(), nrhs,
-                           (int)nrhs, nchunks);
+        if (lv.nclusters)  // clusters and block tasks of one level are independent of each other
+            hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * nchunks)), dim3(64),
+                               (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs, P.cluster_slots);
+        if (lv.ntasks) {
+            const i64 waves = (i64)lv.ntasks * nchunks;
+            const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+            hipLaunchKernelGGL(dev::solve_level_blocked, grid, block, 0, stream, A, lv.task_begin, lv.ntasks, X, ld, scratch_.get(),
+                               nrhs, (int)nrhs, nchunks);
+        }
     }
     RSP_HIP(hipGetLastError());
 }

@@ -1,9 +1,13 @@
-// Builder of the blocked multi-right-hand-side programme (see BlockProgram in sparse.hpp).
+// Builder of the multi-right-hand-side programme (see BlockProgram in sparse.hpp).
 // Integer/host work only; no counterpart in the reference, whose solves are sequential loops
 // (/root/reference/src/lib.rs:464-512, 1230-1278).  The arithmetic each unknown receives is the same
 // set of multiply-subtracts as in those loops, regrouped; for chains replaced by an explicit inverse
 // the diagonal block is applied as M^-1 instead of by substitution (results agree to rounding).
+//
+// Everything here is valid for ANY triangular pattern (LU factors with unsorted rows included): the forest
+// used to pick clusters is only a heuristic, dependencies and levels are always taken from the real entries.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "sparse.hpp"
@@ -17,27 +21,41 @@ constexpr int32_t kNone = BlockProgram::kNone;
 inline int class_of(i64 rows) { return rows <= 1 ? 1 : rows <= 2 ? 2 : rows <= 4 ? 4 : 16; }
 
 struct Triple {
-    int32_t pos;   // processing position of the source (or scratch ordinal for B blocks)
+    int32_t pos;   // processing position of the source (or scratch ordinal for phase-B blocks)
     int32_t slot;  // row slot inside the block
     double val;
 };
 
 class Builder {
    public:
-    Builder(const GatherForm &G, i64 cap) : G_(G), n_(G.n), cap_(cap)
+    Builder(const GatherForm &G, i64 max_blocks, int slots)
+        : G_(G), n_(G.n), max_blocks_(std::max<i64>(1, max_blocks)), slots_(slots)
     {
         avail_.assign(n_, 0);
         task_of_.assign(n_, -1);
         stamp_.assign(n_, -1);
+        cluster_of_.assign(n_, -1);
     }
 
     BlockProgram run()
     {
-        find_runs();
-        for (size_t k = 0; k + 1 < run_begin_.size(); ++k) {
-            const i64 t0 = run_begin_[k], t1 = run_begin_[k + 1];
-            if (t1 - t0 > kBigChain) emit_big_chain(t0, t1);
-            else emit_normal_run(t0, t1);
+        if (slots_ >= 2) select_clusters();
+        std::vector<char> emitted(cluster_lo_.size(), 0);
+        for (i64 t = 0; t < n_;) {
+            const i64 r = row_at(t);
+            const int32_t c = cluster_of_[r];
+            if (c >= 0) {
+                if (!emitted[c]) {
+                    emit_cluster(c);
+                    emitted[c] = 1;
+                }
+                ++t;
+                continue;
+            }
+            i64 t1 = t;  // maximal segment of consecutive unknowns that are not in a cluster
+            while (t1 < n_ && cluster_of_[row_at(t1)] < 0) ++t1;
+            emit_segment(t, t1);
+            t = t1;
         }
         finish();
         return std::move(P_);
@@ -47,24 +65,178 @@ class Builder {
     i64 row_at(i64 t) const { return G_.descending ? n_ - 1 - t : t; }
     i64 pos_of(i64 r) const { return G_.descending ? n_ - 1 - r : r; }
 
-    // maximal runs of consecutive unknowns in which each one depends on ALL earlier ones of the run
-    void find_runs()
+    // ---- clusters ------------------------------------------------------------------------------------------
+    // Forest in index space with the root towards larger indices: parent[j] = smallest index > j related to j
+    // (the first unknown that uses x[j] in ascending solves, the nearest dependency in descending ones).  For a
+    // Cholesky factor this is the elimination tree, whose subtrees are index ranges (the ordering is a postorder).
+    void select_clusters()
     {
-        std::vector<i64> mark(n_, -1);
-        i64 t0 = 0, run = 0;
-        run_begin_.push_back(0);
-        for (i64 t = 0; t < n_; ++t) {
-            const i64 r = row_at(t);
-            i64 inside = 0;
-            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) inside += mark[G_.idx[p]] == run;
-            if (t > t0 && inside != t - t0) {
-                run_begin_.push_back(t);
-                t0 = t;
-                ++run;
-            }
-            mark[r] = run;
+        std::vector<i64> parent(n_, -1);
+        if (!G_.descending) {
+            for (i64 i = 0; i < n_; ++i)
+                for (i64 p = G_.ptr[i]; p < G_.ptr[i + 1]; ++p)
+                    if (parent[G_.idx[p]] < 0) parent[G_.idx[p]] = i;
+        } else {
+            for (i64 j = 0; j < n_; ++j)
+                for (i64 p = G_.ptr[j]; p < G_.ptr[j + 1]; ++p)
+                    if (parent[j] < 0 || G_.idx[p] < parent[j]) parent[j] = G_.idx[p];
         }
-        if (n_ > 0) run_begin_.push_back(n_);
+        std::vector<i64> size(n_, 1), first(n_);
+        for (i64 j = 0; j < n_; ++j) first[j] = j;
+        for (i64 j = 0; j < n_; ++j) {
+            const i64 p = parent[j];
+            if (p < 0) continue;
+            size[p] += size[j];
+            first[p] = std::min(first[p], first[j]);
+        }
+        // maximal subtrees that are index ranges and fit the slot budget (own unknowns + estimated external sources)
+        std::vector<i64> unit_root(n_, -1);
+        for (i64 j = n_ - 1; j >= 0; --j) {
+            const i64 p = parent[j];
+            if (p >= 0 && unit_root[p] >= 0) {
+                unit_root[j] = unit_root[p];
+                continue;
+            }
+            const i64 ext = G_.descending ? G_.ptr[j + 1] - G_.ptr[j] : 0;
+            if (first[j] == j - size[j] + 1 && size[j] + ext <= slots_) unit_root[j] = j;
+        }
+        // pack index-adjacent units into clusters while the exact slot count fits.  A cluster is always an index
+        // range, so its external sources lie strictly before it in processing order and cannot depend on it.
+        i64 a = -1, b = -1;  // current cluster range
+        auto close = [&]() {
+            if (a < 0) return;
+            const int32_t c = (int32_t)cluster_lo_.size();
+            cluster_lo_.push_back(a);
+            cluster_hi_.push_back(b);
+            for (i64 r = a; r <= b; ++r) cluster_of_[r] = c;
+            a = b = -1;
+        };
+        for (i64 i = 0; i < n_;) {
+            const i64 root = unit_root[i];
+            if (root < 0) {
+                close();
+                ++i;
+                continue;
+            }
+            const i64 lo = i, hi = root;  // the unit (i == first[root] by construction)
+            if (a >= 0 && lo == b + 1 && slots_needed(a, hi) <= slots_) {
+                b = hi;
+            } else {
+                close();
+                if (slots_needed(lo, hi) <= slots_) {
+                    a = lo;
+                    b = hi;
+                }
+            }
+            i = hi + 1;
+        }
+        close();
+    }
+
+    // unknowns of [lo, hi] plus their distinct sources outside the range
+    i64 slots_needed(i64 lo, i64 hi)
+    {
+        if (hi - lo + 1 > slots_) return hi - lo + 1;
+        ++stamp_id_;
+        i64 ext = 0;
+        for (i64 r = lo; r <= hi; ++r)
+            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                const i64 s = G_.idx[p];
+                if (s >= lo && s <= hi) continue;
+                if (stamp_[s] != stamp_id_) {
+                    stamp_[s] = stamp_id_;
+                    ++ext;
+                }
+            }
+        return hi - lo + 1 + ext;
+    }
+
+    void emit_cluster(int32_t c)
+    {
+        close_task();
+        const i64 lo = cluster_lo_[c], hi = cluster_hi_[c];
+        const i64 n_own = hi - lo + 1;
+        if (slot_.empty()) slot_.assign(n_, -1);
+        // external sources in first-use order
+        std::vector<int32_t> ext;
+        ++stamp_id_;
+        i64 level = 0;
+        for (i64 k = 0; k < n_own; ++k) {
+            const i64 r = G_.descending ? hi - k : lo + k;
+            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                const i64 s = G_.idx[p];
+                if (s >= lo && s <= hi) continue;
+                if (stamp_[s] != stamp_id_) {
+                    stamp_[s] = stamp_id_;
+                    slot_[s] = (int32_t)ext.size();
+                    ext.push_back((int32_t)s);
+                    level = std::max<i64>(level, avail_[s] + 1);
+                }
+            }
+        }
+        ClusterHeader h{(int32_t)ext.size(), (int32_t)n_own, 0, 0, (i64)P_.cluster_ids.size(), (i64)P_.groups.size()};
+        P_.cluster_ids.insert(P_.cluster_ids.end(), ext.begin(), ext.end());
+        for (i64 k = 0; k < n_own; ++k) {
+            const i64 r = G_.descending ? hi - k : lo + k;
+            slot_[r] = (int32_t)(ext.size() + k);
+            P_.cluster_ids.push_back((int32_t)r);
+        }
+        for (i64 k = 0; k < n_own; ++k) {
+            const i64 r = G_.descending ? hi - k : lo + k;
+            const int32_t own_off = slot_[r] * 512;
+            const i64 pb = G_.ptr[r], ne = G_.ptr[r + 1] - pb;
+            const i64 ng = std::max<i64>(1, (ne + 3) / 4);
+            for (i64 g = 0; g < ng; ++g) {
+                GroupRec rec;
+                const i64 cnt = std::max<i64>(0, std::min<i64>(4, ne - 4 * g));
+                for (i64 e = 0; e < 4; ++e) {
+                    if (e < cnt) {
+                        rec.off[e] = slot_[G_.idx[pb + 4 * g + e]] * 512;
+                        rec.coef[e] = G_.val[pb + 4 * g + e];
+                    } else {
+                        rec.off[e] = own_off;
+                        rec.coef[e] = 0.0;
+                    }
+                }
+                rec.rdiag = 1.0 / G_.diag[r];
+                rec.own_off = own_off;
+                rec.flags = (int32_t)cnt | (g == 0 ? GroupRec::kFirst : 0) | (g == ng - 1 ? GroupRec::kLast : 0);
+                P_.groups.push_back(rec);
+            }
+            avail_[r] = (int32_t)level;
+            task_of_[r] = -2;
+            P_.cluster_entries += ne;
+        }
+        h.ngroups = (int32_t)((i64)P_.groups.size() - h.grp_off);
+        P_.clusters.push_back(h);
+        cluster_level_.push_back((int32_t)level);
+        emit_order_.push_back(c);
+        P_.cluster_rows += n_own;
+        P_.cluster_slots = std::max<int32_t>(P_.cluster_slots, h.n_ext + h.n_own);
+    }
+
+    // ---- segments of unknowns outside clusters: maximal runs in which each unknown depends on ALL earlier ones ----
+    void emit_segment(i64 s0, i64 s1)
+    {
+        if (mark_.empty()) mark_.assign(n_, -1);
+        i64 t0 = s0;
+        ++run_id_;
+        for (i64 t = s0; t <= s1; ++t) {
+            bool cut = (t == s1);
+            if (!cut && t > t0) {
+                const i64 r = row_at(t);
+                i64 inside = 0;
+                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) inside += mark_[G_.idx[p]] == run_id_;
+                cut = inside != t - t0;
+            }
+            if (cut) {
+                if (t - t0 > kBigChain) emit_big_chain(t0, t);
+                else emit_normal_run(t0, t);
+                t0 = t;
+                ++run_id_;
+            }
+            if (t < s1) mark_[row_at(t)] = run_id_;
+        }
     }
 
     // ---- low-level emission ------------------------------------------------------------------------
@@ -88,7 +260,7 @@ class Builder {
             for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] = src[k].val;
             ++ns;
         }
-        if (rc == 16)  // the matrix-core path consumes sources sixteen at a time: pad with zero coefficients
+        if (rc == 16 && ns > 0)  // the matrix-core path consumes sources sixteen at a time: pad with zero coefficients
             for (; ns % 16 != 0; ++ns) {
                 P_.src_idx.push_back(P_.src_idx.back());
                 P_.coef.resize(P_.coef.size() + rc, 0.0);
@@ -123,7 +295,6 @@ class Builder {
                 for (int l = 0; l < 64; ++l) P_.coef[base + (size_t)k * 64 + l] = Ti[l & 15][4 * k + (l >> 4)];
         }
         P_.padded_entries += ns * rc;
-        blk_entries_.push_back(ns * rc + (tri ? rc * rc / 2 : 0));
         if (own_task) {
             close_task();
             task_first_blk_.push_back(b);
@@ -205,22 +376,13 @@ class Builder {
                 }
             }
         }
-        // distinct sources (for the task's work bound)
-        i64 uniq = 0;
-        {
-            ++stamp_id_;
-            for (const Triple &x : src_) {
-                const i64 s = row_at(x.pos);
-                if (stamp_[s] != stamp_id_) { stamp_[s] = stamp_id_; ++uniq; }
-            }
-        }
-        const i64 work = uniq * class_of(rows) + rows * rows / 2 + 1;
-        const bool fits = cur_task_ >= 0 && cur_work_ + work <= cap_;
+        // a wavefront runs at most max_blocks_ dependent blocks back to back: every block costs a chain of dependent
+        // global loads (header, ids, rows), so longer tasks stretch the level they run in
+        const bool fits = cur_task_ >= 0 && task_nblk_[cur_task_] < max_blocks_;
         i64 level;
         if (fits && need <= task_level_[cur_task_] && (chained || need == task_level_[cur_task_])) {
             level = task_level_[cur_task_];
             task_nblk_[cur_task_]++;
-            cur_work_ += work;
         } else {
             if (cur_task_ >= 0 && chained) need = std::max<i64>(need, task_level_[cur_task_] + 1);
             level = need;
@@ -228,7 +390,6 @@ class Builder {
             task_first_blk_.push_back((i64)P_.hdr.size());
             task_level_.push_back((int32_t)level);
             task_nblk_.push_back(1);
-            cur_work_ = work;
         }
         const i64 keep_task = cur_task_;
         push_block(rows, dest, dest, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, tri, level, false);
@@ -237,49 +398,6 @@ class Builder {
             avail_[row_at(t)] = (int32_t)level;
             task_of_[row_at(t)] = (int32_t)cur_task_;
         }
-    }
-
-    // ---- gather with optional split into partial sums; every block is its own task -------------------------
-    // src triples: pos = ordinal understood by id_of.  Returns the level at which dest is complete.
-    template <class IdOf>
-    i64 emit_gather(int rows, const int32_t *dest, const int32_t *init, std::vector<Triple> &src, IdOf id_of, i64 level)
-    {
-        std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
-        // count distinct sources
-        i64 ns = 0;
-        for (size_t k = 0; k < src.size(); ++k) ns += (k == 0 || src[k].pos != src[k - 1].pos);
-        if (ns <= kChunkSources) {
-            push_block(rows, dest, init, src, id_of, nullptr, level, true);
-            return level;
-        }
-        const i64 parts = (ns + kChunkSources - 1) / kChunkSources;
-        const i64 per = (ns + parts - 1) / parts;
-        std::vector<int32_t> pdest((size_t)parts * rows);
-        std::vector<Triple> chunk;
-        size_t k = 0;
-        for (i64 p = 0; p < parts; ++p) {
-            chunk.clear();
-            i64 taken = 0;
-            while (k < src.size()) {
-                const bool new_src = (chunk.empty() || src[k].pos != chunk.back().pos);
-                if (new_src && taken == per) break;
-                taken += new_src;
-                chunk.push_back(src[k++]);
-            }
-            int32_t none[16];
-            for (int r = 0; r < rows; ++r) {
-                pdest[(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
-                none[r] = kNone;
-            }
-            push_block(rows, &pdest[(size_t)p * rows], p == 0 ? init : none, chunk, id_of, nullptr, level, true);
-        }
-        // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial)
-        std::vector<Triple> comb;
-        for (i64 p = 1; p < parts; ++p)
-            for (int r = 0; r < rows; ++r) comb.push_back(Triple{(int32_t)((p - 1) * rows + r), r, -1.0});
-        const int32_t *p1 = pdest.data() + rows;
-        push_block(rows, dest, pdest.data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, level + 1, true);
-        return level + 1;
     }
 
     // ---- long dense chains: Y = X_J - L[J,ext] X_ext ; X_J = M^-1 Y ------------------------------------------
@@ -313,7 +431,7 @@ class Builder {
         }
         const i64 y0 = P_.scratch_rows;
         P_.scratch_rows += w;
-        // phase A per group of 16 unknowns
+        // phase A per group of 16 unknowns: all groups independent
         i64 ready = 0;
         for (i64 a = t0; a < t1; a += 16) {
             const i64 b = std::min(a + 16, t1);
@@ -334,11 +452,10 @@ class Builder {
                     need = std::max<i64>(need, avail_[s] + 1);
                 }
             }
-            const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, need);
-            ready = std::max(ready, done);
+            push_block(rows, dest, init, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, nullptr, need, true);
+            ready = std::max(ready, need);
         }
         // phase B: X_J = Minv * Y, all groups independent
-        i64 final_level = ready + 1;
         for (i64 a = t0; a < t1; a += 16) {
             const i64 b = std::min(a + 16, t1);
             const int rows = (int)(b - a);
@@ -351,28 +468,43 @@ class Builder {
                 const double *Mi = &Minv[(size_t)(t - t0) * w];
                 for (i64 u = 0; u <= t - t0; ++u) src_.push_back(Triple{(int32_t)u, slot, -Mi[u]});
             }
-            const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
-            final_level = std::max(final_level, done);
+            push_block(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, nullptr, ready + 1, true);
         }
         for (i64 t = t0; t < t1; ++t) {
-            avail_[row_at(t)] = (int32_t)final_level;
+            avail_[row_at(t)] = (int32_t)(ready + 1);
             task_of_[row_at(t)] = -2;  // never "chained" to a running task
         }
         close_task();
     }
 
-    // ---- order tasks by level and blocks by task ---------------------------------------------------------
+    // ---- order tasks and clusters by level ------------------------------------------------------------------
     void finish()
     {
-        const i64 ntasks = (i64)task_level_.size();
+        const i64 ntasks = (i64)task_level_.size(), nclusters = (i64)cluster_level_.size();
         i64 nlev = 0;
         for (int32_t l : task_level_) nlev = std::max<i64>(nlev, l + 1);
+        for (int32_t l : cluster_level_) nlev = std::max<i64>(nlev, l + 1);
+        // clusters nothing else reads (the leaves of a transposed solve) all run in ONE launch at the last level
+        if (nclusters) {
+            std::vector<char> read(nclusters, 0);
+            for (int32_t id : P_.src_idx)
+                if (id >= 0 && cluster_of_[id] >= 0) read[cluster_of_[id]] = 1;
+            for (i64 c = 0; c < nclusters; ++c) {
+                const ClusterHeader &h = P_.clusters[c];
+                for (int32_t e = 0; e < h.n_ext; ++e) {
+                    const int32_t id = P_.cluster_ids[h.ids_off + e];
+                    if (cluster_of_[id] >= 0) read[cluster_of_[id]] = 1;
+                }
+            }
+            // P_.clusters / cluster_level_ are in emission (processing) order, read[] is indexed by cluster id
+            for (i64 c = 0; c < nclusters; ++c)
+                if (!read[emit_order_[c]]) cluster_level_[c] = (int32_t)(nlev - 1);
+        }
         P_.level_ptr.assign(nlev + 1, 0);
         for (int32_t l : task_level_) P_.level_ptr[l + 1]++;
         for (i64 l = 0; l < nlev; ++l) P_.level_ptr[l + 1] += P_.level_ptr[l];
         std::vector<i64> fill(P_.level_ptr.begin(), P_.level_ptr.end() - 1), order(ntasks);
         for (i64 t = 0; t < ntasks; ++t) order[fill[task_level_[t]]++] = t;
-        // permute the per-block arrays into task order
         std::vector<BlockHeader> hdr(P_.hdr.size());
         P_.task_ptr.assign(ntasks + 1, 0);
         i64 at = 0;
@@ -383,29 +515,182 @@ class Builder {
         }
         P_.task_ptr[ntasks] = at;
         P_.hdr.swap(hdr);
+        // clusters
+        P_.cluster_level_ptr.assign(nlev + 1, 0);
+        for (int32_t l : cluster_level_) P_.cluster_level_ptr[l + 1]++;
+        for (i64 l = 0; l < nlev; ++l) P_.cluster_level_ptr[l + 1] += P_.cluster_level_ptr[l];
+        std::vector<i64> cfill(P_.cluster_level_ptr.begin(), P_.cluster_level_ptr.end() - 1);
+        std::vector<ClusterHeader> ch(nclusters);
+        for (i64 c = 0; c < nclusters; ++c) ch[cfill[cluster_level_[c]]++] = P_.clusters[c];
+        P_.clusters.swap(ch);
     }
 
     const GatherForm &G_;
-    const i64 n_, cap_;
+    const i64 n_, max_blocks_;
+    const int slots_;
     BlockProgram P_;
-    std::vector<i64> run_begin_;
-    std::vector<int32_t> avail_, task_of_;
-    std::vector<i64> stamp_;
-    i64 stamp_id_ = 0;
+    std::vector<int32_t> avail_, task_of_, cluster_of_, slot_;
+    std::vector<i64> stamp_, mark_;
+    i64 stamp_id_ = 0, run_id_ = 0;
     std::vector<Triple> src_;
-    std::vector<i64> blk_entries_;
-    // tasks in creation order
+    std::vector<i64> cluster_lo_, cluster_hi_;
+    std::vector<int32_t> cluster_level_;  // in emission order
+    std::vector<int32_t> emit_order_;     // emission order -> cluster id (index into cluster_lo_)
+    // block tasks in creation order
     std::vector<i64> task_first_blk_, task_nblk_;
     std::vector<int32_t> task_level_;
-    i64 cur_task_ = -1, cur_work_ = 0;
+    i64 cur_task_ = -1;
 };
 
 }  // namespace
 
-BlockProgram build_block_program(const GatherForm &G, i64 max_task_entries)
+BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots)
 {
-    Builder b(G, max_task_entries);
+    Builder b(G, max_task_blocks, cluster_slots);
     return b.run();
+}
+
+ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P)
+{
+    ProgramReport R;
+    const i64 n = G.n;
+    // synthetic right-hand side and the sequential answer
+    std::vector<double> b(n), want(n);
+    uint64_t z = 0x9E3779B97F4A7C15ull;
+    for (i64 i = 0; i < n; ++i) {
+        z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+        b[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+    }
+    want = b;
+    for (i64 t = 0; t < n; ++t) {
+        const i64 r = G.descending ? n - 1 - t : t;
+        double acc = want[r];
+        for (i64 p = G.ptr[r]; p < G.ptr[r + 1]; ++p) acc -= G.val[p] * want[G.idx[p]];
+        want[r] = acc / G.diag[r];
+    }
+    std::vector<double> x = b, scratch((size_t)std::max<i64>(P.scratch_rows, 1), 0.0);
+    // level at which a row of X / scratch becomes final (-1: initial data, INT_MAX: not yet written)
+    std::vector<i64> xdone(n, INT32_MAX), sdone((size_t)std::max<i64>(P.scratch_rows, 1), INT32_MAX);
+    std::vector<int> writes(n, 0);
+    std::vector<i64> xtask(n, -1), stask((size_t)std::max<i64>(P.scratch_rows, 1), -1);  // block task that wrote the row
+    auto producer = [&](int32_t id) -> i64 & { return id >= 0 ? xtask[id] : stask[~id]; };
+    const i64 nlev = (i64)P.level_ptr.size() - 1;
+    auto valid = [&](int32_t id) { return id >= 0 ? id < n : (id != BlockProgram::kNone && (i64)(~id) < P.scratch_rows); };
+    auto value = [&](int32_t id) -> double & { return id >= 0 ? x[id] : scratch[~id]; };
+    auto done = [&](int32_t id) -> i64 & { return id >= 0 ? xdone[id] : sdone[~id]; };
+    for (i64 l = 0; l < nlev; ++l) {
+        // ---- clusters of this level ----
+        for (i64 c = P.cluster_level_ptr[l]; c < P.cluster_level_ptr[l + 1]; ++c) {
+            const ClusterHeader &h = P.clusters[c];
+            const i64 ns = h.n_ext + h.n_own;
+            if (ns > P.cluster_slots || h.ids_off < 0 || h.ids_off + ns > (i64)P.cluster_ids.size() || h.grp_off < 0 ||
+                h.grp_off + h.ngroups > (i64)P.groups.size() || h.ngroups < 1) {
+                ++R.bad_index;
+                continue;
+            }
+            std::vector<double> lds(ns);
+            bool ok = true;
+            for (i64 s = 0; s < ns; ++s) {
+                const int32_t id = P.cluster_ids[h.ids_off + s];
+                if (id < 0 || id >= n) { ++R.bad_index; ok = false; break; }
+                if (s < h.n_ext && xdone[id] >= l) ++R.order_violations;   // external source not final yet
+                if (s >= h.n_ext && xdone[id] != INT32_MAX) ++R.unwritten;  // own unknown already written
+                lds[s] = x[id];
+            }
+            if (!ok) continue;
+            double acc = 0.0;
+            for (i64 g = 0; g < h.ngroups; ++g) {
+                const GroupRec &rec = P.groups[h.grp_off + g];
+                const i64 own = rec.own_off / 512;
+                if (rec.own_off % 512 || own < h.n_ext || own >= ns) { ++R.bad_index; break; }
+                if (rec.flags & GroupRec::kFirst) acc = lds[own];
+                if (rec.flags & 7)
+                    for (int e = 0; e < 4; ++e) {
+                        const i64 s = rec.off[e] / 512;
+                        if (rec.off[e] % 512 || s < 0 || s >= ns) { ++R.bad_index; continue; }
+                        acc -= rec.coef[e] * lds[s];
+                    }
+                if (rec.flags & GroupRec::kLast) { acc *= rec.rdiag; lds[own] = acc; }
+            }
+            for (i64 s = h.n_ext; s < ns; ++s) {
+                const int32_t id = P.cluster_ids[h.ids_off + s];
+                x[id] = lds[s];
+                xdone[id] = l;
+                writes[id]++;
+            }
+        }
+        // ---- block tasks of this level ----
+        for (i64 t = P.level_ptr[l]; t < P.level_ptr[l + 1]; ++t) {
+            for (i64 bk = P.task_ptr[t]; bk < P.task_ptr[t + 1]; ++bk) {
+                const BlockHeader &h = P.hdr[bk];
+                const int rc = h.rc;
+                if ((rc != 1 && rc != 2 && rc != 4 && rc != 16) || h.src_off < 0 ||
+                    h.src_off + 2 * rc + h.nsrc > (i64)P.src_idx.size() || h.coef_off < 0 ||
+                    h.coef_off + (i64)h.nsrc * rc + (h.has_tri ? (rc == 16 ? 256 : rc * rc) : 0) > (i64)P.coef.size() ||
+                    (rc == 16 && h.nsrc % 16)) {
+                    ++R.bad_index;
+                    continue;
+                }
+                const int32_t *ids = P.src_idx.data() + h.src_off;
+                const double *cf = P.coef.data() + h.coef_off;
+                double acc[16];
+                for (int r = 0; r < rc; ++r) {
+                    const int32_t id = ids[rc + r];
+                    acc[r] = 0.0;
+                    if (id == BlockProgram::kNone) continue;
+                    if (!valid(id)) { ++R.bad_index; continue; }
+                    // init rows: initial data of X (never written before) or a scratch row final at a lower level
+                    if (id < 0 && done(id) >= l) ++R.order_violations;
+                    acc[r] = value(id);
+                }
+                for (i64 e = 0; e < h.nsrc; ++e) {
+                    const int32_t id = ids[2 * rc + e];
+                    if (!valid(id)) { ++R.bad_index; continue; }
+                    bool zero = true;
+                    for (int r = 0; r < rc; ++r) zero = zero && cf[e * rc + r] == 0.0;
+                    // final at a lower level, or written earlier by this very task (marked with level l during the task)
+                    if (!zero && done(id) > l) ++R.order_violations;
+                    if (!zero && done(id) == l && producer(id) != t) ++R.order_violations;
+                    for (int r = 0; r < rc; ++r) acc[r] -= cf[e * rc + r] * value(id);
+                }
+                if (h.has_tri) {
+                    const double *tri = cf + (i64)h.nsrc * rc;
+                    if (rc < 16) {
+                        for (int r = 0; r < rc; ++r) {
+                            for (int u = 0; u < r; ++u) acc[r] -= tri[r * rc + u] * acc[u];
+                            acc[r] /= tri[r * rc + r];
+                        }
+                    } else {
+                        double out[16];
+                        for (int r = 0; r < 16; ++r) {
+                            double s = 0.0;
+                            for (int u = 0; u < 16; ++u) s += tri[(u / 4) * 64 + (u % 4) * 16 + r] * acc[u];
+                            out[r] = s;
+                        }
+                        std::copy(out, out + 16, acc);
+                    }
+                }
+                for (int r = 0; r < rc; ++r) {
+                    const int32_t id = ids[r];
+                    if (id == BlockProgram::kNone) continue;
+                    if (!valid(id)) { ++R.bad_index; continue; }
+                    value(id) = acc[r];
+                    done(id) = l;
+                    if (id >= 0) writes[id]++;
+                    producer(id) = t;
+                }
+            }
+        }
+    }
+    double top = 1e-300, err = 0.0;
+    for (i64 i = 0; i < n; ++i) {
+        if (writes[i] != 1) ++R.unwritten;
+        top = std::max(top, std::fabs(want[i]));
+        const double e = std::fabs(x[i] - want[i]);
+        if (!(e <= err)) err = e;  // NaN propagates
+    }
+    R.max_rel_error = err / top;
+    return R;
 }
 
 }  // namespace rsp

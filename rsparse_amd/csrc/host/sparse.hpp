@@ -111,19 +111,25 @@ struct Schedule {
 Schedule build_schedule(const GatherForm &G, i64 max_task_entries);
 
 // ---- blocked.cpp ----------------------------------------------------------------------------------
-// The multi-right-hand-side programme.  Unknowns are grouped into BLOCKS of up to 16 unknowns that are
-// consecutive in processing order and share most of their sources (supernode rows).  A block is one unit of
-// work for a wavefront:
+// The multi-right-hand-side programme.  Unknowns are split into two kinds of work:
+//
+// CLUSTERS (bottom of the dependency forest): a run of consecutive unknowns -- whole small subtrees -- that one
+// wavefront solves start to finish with the rows of X it touches held in LDS ("slots": external sources first, then
+// the cluster's own unknowns in processing order).  The arithmetic is streamed as 64-byte GROUP records (up to four
+// multiply-subtracts each) that the wavefront prefetches several records ahead; nothing on the dependent chain of a
+// cluster waits on global memory, so the thousands of short dependent rows at the bottom cost LDS latency, not HBM latency.
+//
+// BLOCKS (everything above): up to 16 unknowns that are consecutive in processing order and share most of their
+// sources (supernode rows).  A block is one unit of work for a wavefront:
 //     acc[r] = init[r]  (a row of X, a scratch row, or 0)                         r < rc
 //     acc[r] -= coef[e][r] * src[e]     for every source e of the block (a row of X or a scratch row)
 //     if has_tri:  acc[r] = (acc[r] - sum_{t<r} tri[r][t] * acc[t]) / tri[r][r]   (the block's own chain)
 //     dest[r] = acc[r]
-// so every source row is loaded once and used for rc unknowns (register reuse), and the coefficients are
-// wave-uniform scalars.  Long dense chains (supernodes wider than kBigChain) are not solved sequentially:
-// their diagonal block M is inverted on the host once, and the chain becomes two sets of independent blocks,
+// so every source row is loaded once and used for rc unknowns (register reuse).  Long dense chains (supernodes wider
+// than kBigChain) are not solved sequentially: their diagonal block M is inverted on the host once, and the chain
+// becomes two sets of independent blocks,
 //     Y = X_J - L[J, ext] X_ext   (scratch)      and      X_J = M^-1 Y,
-// which removes the chain from the critical path.  Source lists longer than kChunkSources are split into
-// partial sums (scratch rows) that a small combine block adds up.
+// which removes the chain from the critical path.
 struct BlockHeader {   // 32 bytes: the device reads it with one scalar load
     int32_t rc;        // class size: 1, 2, 4 (vector path) or 16 (matrix-core path); rows padded with kNone
     int32_t nsrc;      // number of sources; rc == 16: padded to a multiple of 16 with zero coefficients
@@ -132,20 +138,54 @@ struct BlockHeader {   // 32 bytes: the device reads it with one scalar load
     i64 src_off;       // into src_idx: [rc destination ids][rc init ids][nsrc source ids]
     i64 coef_off;      // into coef: nsrc*rc source coefficients, then the triangle (rc*rc, or 256 for rc == 16)
 };
+struct ClusterHeader {  // 32 bytes
+    int32_t n_ext;      // slots [0, n_ext): external sources (read only)
+    int32_t n_own;      // slots [n_ext, n_ext + n_own): the cluster's unknowns, in processing order (written back)
+    int32_t ngroups;
+    int32_t pad;
+    i64 ids_off;        // into cluster_ids: the row of X behind every slot
+    i64 grp_off;        // into groups
+};
+struct GroupRec {       // 64 bytes: four 16-byte loads, the same address in every lane
+    int32_t off[4];     // LDS byte offset (slot * 512) of each source; unused entries repeat a valid slot with coef 0
+    double coef[4];
+    double rdiag;       // 1 / diagonal, applied when kLast is set
+    int32_t own_off;    // LDS byte offset of the unknown this group belongs to
+    int32_t flags;      // bits 0-2: number of valid entries (0..4); kFirst: start of an unknown; kLast: divide and store
+    static constexpr int32_t kFirst = 8, kLast = 16;
+};
 struct BlockProgram {
     static constexpr int32_t kNone = INT32_MIN;
     std::vector<BlockHeader> hdr;    // per block
     // pools
     std::vector<int32_t> src_idx;    // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
     std::vector<double> coef;
+    // clusters, sorted by level
+    std::vector<ClusterHeader> clusters;
+    std::vector<int32_t> cluster_ids;
+    std::vector<GroupRec> groups;
+    int32_t cluster_slots = 0;       // LDS slots a wavefront needs (max n_ext + n_own over all clusters)
     // schedule
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
-    std::vector<i64> level_ptr;      // tasks of level l
+    std::vector<i64> level_ptr;      // block tasks of level l
+    std::vector<i64> cluster_level_ptr;  // clusters of level l (same level numbering)
     i64 scratch_rows = 0;
-    i64 big_chains = 0, inverted_rows = 0, padded_entries = 0;
+    i64 big_chains = 0, inverted_rows = 0, padded_entries = 0, cluster_rows = 0, cluster_entries = 0;
 };
 constexpr i64 kBigChain = 32;        // chains longer than this are replaced by their inverse
-constexpr i64 kChunkSources = 256;   // sources per partial block
-BlockProgram build_block_program(const GatherForm &G, i64 max_task_entries);
+constexpr int kClusterSlots = 48;    // default LDS slots per cluster (24 KB per wavefront at 64 right-hand sides)
+constexpr i64 kTaskBlocks = 2;       // default number of dependent blocks one wavefront runs back to back
+BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots);
+
+// Host-side validator of a programme (debug aid, never a solve path: it takes no user data).  Replays the programme
+// level by level on ONE synthetic right-hand side with every index bounds-checked and every read checked against the
+// level that produces it, and compares with plain sequential substitution over the gather form.
+struct ProgramReport {
+    i64 bad_index = 0;        // ids / offsets outside their arrays
+    i64 order_violations = 0; // a row read before the level (or the earlier block of the same task) that writes it
+    i64 unwritten = 0;        // unknowns no block or cluster writes, or written more than once
+    double max_rel_error = 0; // against sequential substitution
+};
+ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P);
 
 }  // namespace rsp
