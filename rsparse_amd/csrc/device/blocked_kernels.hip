@@ -97,6 +97,7 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const BlockAr
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // ---- matrix-core path: 16 unknowns x 64 right-hand sides ----------------------------------------------------
 // acc lives in the C/D layout of v_mfma_f64_16x16x4_f64: lane (g = lane >> 4, j = lane & 15), register s <-> unknown
@@ -105,64 +106,119 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // 512-byte read of the coefficient stream), B = the gathered rows (lane (g, j): 4 doubles of source 4k+g).
 // The in-block triangular solve is 4 more K-steps with A = inverse of the block's 16 x 16 triangle and B = acc itself
 // (C/D register s IS the B operand of K-step s), so nothing ever crosses lanes.
-__device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockArrays &B, double *X, int64_t ldx, double *S, int64_t lds,
-                                               int cw, int nrhs, int lane)
+//
+// Sources are consumed in STAGES of 16 (4 K-steps, 16 MFMAs).  The loads of stage s+1 (16 row pieces, 4 coefficient
+// vectors) and the ids of stage s+2 are issued before the MFMAs of stage s; every load is unconditional (stage numbers
+// are clamped), so the compiler's vmcnt bookkeeping stays exact and a stage's MFMAs wait for that stage's loads only.
+struct Stage {
+    double a[4];
+    f64x2 lo[4], hi[4];
+};
+
+struct PanelCtx {
+    const int32_t *sidx;  // source ids of the block
+    const double *cf;     // source coefficients of the block
+    const double *X, *S;
+    int64_t ldx, lds;
+    int g, lane, cb, nrhs;
+    bool in;              // this lane's 4 columns exist (FAST: all or none)
+};
+
+__device__ __forceinline__ void load_ids(int32_t (&id)[4], const PanelCtx &c, int st)
 {
-    const int g = lane >> 4, j = lane & 15;
-    const int cb = cw + 4 * j;
-    const bool full = cb + 4 <= nrhs;
-    const int32_t *ids = B.src_idx + h.src_off;
-    const double *cf = B.coef + h.coef_off;
-    const int32_t hid = ids[lane < 32 ? lane : 0];  // 16 dest ids, 16 init ids
-    f64x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) id[q] = c.sidx[st * 16 + 4 * q + c.g];
+}
+
+template <bool FAST>
+__device__ __forceinline__ void load_stage(Stage &R, const int32_t (&id)[4], const PanelCtx &c, int st)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        R.a[q] = -c.cf[(int64_t)(st * 16 + 4 * q) * 16 + c.lane];
+        const double *p = row_ptr(id[q], c.X, c.ldx, c.S, c.lds);
+        if (FAST) {  // 16-byte aligned rows, nrhs a multiple of 4: lanes without columns re-read column 0
+            p += c.in ? c.cb : 0;
+            R.lo[q] = *reinterpret_cast<const f64x2 *>(p);
+            R.hi[q] = *reinterpret_cast<const f64x2 *>(p + 2);
+        } else {
+            p += c.cb;
+            R.lo[q].x = c.cb + 0 < c.nrhs ? p[0] : 0.0;
+            R.lo[q].y = c.cb + 1 < c.nrhs ? p[1] : 0.0;
+            R.hi[q].x = c.cb + 2 < c.nrhs ? p[2] : 0.0;
+            R.hi[q].y = c.cb + 3 < c.nrhs ? p[3] : 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void mfma_stage(f64x4 (&acc)[4], const Stage &R)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].x, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].y, acc[3], 0, 0, 0);
+    }
+}
+
+// acc -= coef[st_begin*16 .. st_end*16) * sources
+template <bool FAST>
+__device__ __forceinline__ void panel_accumulate(f64x4 (&acc)[4], const PanelCtx &c, int st_begin, int st_end)
+{
+    if (st_begin >= st_end) return;
+    const int last = st_end - 1;
+    int32_t idA[4], idB[4];
+    Stage A, B;
+    load_ids(idA, c, st_begin);
+    load_ids(idB, c, min(st_begin + 1, last));
+    load_stage<FAST>(A, idA, c, st_begin);
+    for (int s = st_begin; s < st_end; s += 2) {
+        load_stage<FAST>(B, idB, c, min(s + 1, last));
+        load_ids(idA, c, min(s + 2, last));
+        mfma_stage(acc, A);
+        load_stage<FAST>(A, idA, c, min(s + 2, last));
+        load_ids(idB, c, min(s + 3, last));
+        if (s + 1 < st_end) mfma_stage(acc, B);
+    }
+}
+
+// rows of the block -> acc (register s <- unknown 4s + g); ids16 = 16 ids, kNone = zero
+template <bool FAST>
+__device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t *ids16, const PanelCtx &c)
+{
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int32_t id = __shfl(hid, 16 + 4 * s + g, 64);
+        const int32_t id = ids16[4 * s + c.g];
         double v[4] = {0.0, 0.0, 0.0, 0.0};
         if (id != RSP_NONE) {
-            const double *p = row_ptr(id, X, ldx, S, lds) + cb;
-            if (full) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) v[nt] = p[nt];
+            const double *p = row_ptr(id, c.X, c.ldx, c.S, c.lds) + c.cb;
+            if (FAST) {
+                if (c.in) {
+                    const f64x2 lo = *reinterpret_cast<const f64x2 *>(p), hi = *reinterpret_cast<const f64x2 *>(p + 2);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+                }
             } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    if (cb + nt < nrhs) v[nt] = p[nt];
+                    if (c.cb + nt < c.nrhs) v[nt] = p[nt];
             }
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt][s] = v[nt];
     }
-    const int32_t *sidx = ids + 32;
-    for (int e0 = 0; e0 < h.nsrc; e0 += 64) {
-        const int nb = min(64, h.nsrc - e0);  // multiple of 16
-        const int32_t idv = sidx[e0 + (lane < nb ? lane : 0)];
-        for (int k0 = 0; k0 < nb; k0 += 16) {  // 4 K-steps = 16 sources: all gathers first, then 16 MFMAs
-            double a[4], xb[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int32_t id = __shfl(idv, k0 + 4 * q + g, 64);
-                a[q] = -cf[(int64_t)(e0 + k0 + 4 * q) * 16 + lane];
-                const double *p = row_ptr(id, X, ldx, S, lds) + cb;
-                if (full) {
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) xb[q][nt] = p[nt];
-                } else {
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) xb[q][nt] = (cb + nt < nrhs) ? p[nt] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], xb[q][nt], acc[nt], 0, 0, 0);
-        }
-    }
+}
+
+// in-block triangle (as its inverse) and the store of the 16 unknowns
+template <bool FAST>
+__device__ __forceinline__ void panel_finish(f64x4 (&acc)[4], const BlockHeader h, const int32_t *ids16, const PanelCtx &c, double *X,
+                                             double *S)
+{
     if (h.has_tri) {
-        const double *tinv = cf + (int64_t)h.nsrc * 16;  // 4 x 64 doubles in A-operand order
+        const double *tinv = c.cf + (int64_t)h.nsrc * 16;  // 4 x 64 doubles in A-operand order
         double a4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = tinv[k * 64 + lane];
+        for (int k = 0; k < 4; ++k) a4[k] = tinv[k * 64 + c.lane];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f64x4 r = {0.0, 0.0, 0.0, 0.0};
@@ -173,24 +229,58 @@ __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockA
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int32_t id = __shfl(hid, 4 * s + g, 64);
+        const int32_t id = ids16[4 * s + c.g];
         if (id != RSP_NONE) {
-            double *p = const_cast<double *>(row_ptr(id, X, ldx, S, lds)) + cb;
-            if (full) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) p[nt] = acc[nt][s];
+            double *p = const_cast<double *>(row_ptr(id, X, c.ldx, S, c.lds)) + c.cb;
+            if (FAST) {
+                if (c.in) {
+                    *reinterpret_cast<f64x2 *>(p) = f64x2{acc[0][s], acc[1][s]};
+                    *reinterpret_cast<f64x2 *>(p + 2) = f64x2{acc[2][s], acc[3][s]};
+                }
             } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    if (cb + nt < nrhs) p[nt] = acc[nt][s];
+                    if (c.cb + nt < c.nrhs) p[nt] = acc[nt][s];
             }
         }
     }
 }
 
+template <bool FAST>
+__device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArrays &B, const double *X, int64_t ldx, const double *S,
+                                             int64_t lds, int cw, int nrhs, int lane)
+{
+    PanelCtx c;
+    c.sidx = B.src_idx + h.src_off + 32;
+    c.cf = B.coef + h.coef_off;
+    c.X = X;
+    c.S = S;
+    c.ldx = ldx;
+    c.lds = lds;
+    c.g = lane >> 4;
+    c.lane = lane;
+    c.cb = cw + 4 * (lane & 15);
+    c.nrhs = nrhs;
+    c.in = c.cb + 4 <= nrhs;
+    return c;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockArrays &B, double *X, int64_t ldx, double *S, int64_t lds,
+                                               int cw, int nrhs, int lane)
+{
+    const PanelCtx c = make_ctx<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane);
+    const int32_t *ids = B.src_idx + h.src_off;  // 16 dest ids, 16 init ids
+    f64x4 acc[4];
+    panel_load_rows<FAST>(acc, ids + 16, c);
+    panel_accumulate<FAST>(acc, c, 0, h.nsrc >> 4);
+    panel_finish<FAST>(acc, h, ids, c, X, S);
+}
+
 // one wavefront per (task, 64 columns); the blocks of a task run in order
-__global__ __launch_bounds__(256, 4) void solve_level_blocked(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx,
-                                                               double *S, int64_t lds, int nrhs, int nchunks)
+template <bool FAST>
+__global__ __launch_bounds__(256) void solve_level_blocked(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx,
+                                                            double *S, int64_t lds, int nrhs, int nchunks)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -204,11 +294,54 @@ __global__ __launch_bounds__(256, 4) void solve_level_blocked(BlockArrays B, int
     for (int64_t b = B.task_ptr[task_begin + t]; b < bend; ++b) {
         const BlockHeader h = B.hdr[b];
         switch (h.rc) {
-            case 16: run_block_mfma(h, B, X, ldx, S, lds, cw, nrhs, lane); break;
+            case 16: run_block_mfma<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane); break;
             case 1: run_block_vec<1>(h, B, X, ldx, S, lds, col, live, lane); break;
             case 2: run_block_vec<2>(h, B, X, ldx, S, lds, col, live, lane); break;
             default: run_block_vec<4>(h, B, X, ldx, S, lds, col, live, lane); break;
         }
+    }
+}
+
+// W wavefronts per (task, 64 columns): the task is ONE matrix-core block whose stages are dealt to the wavefronts in
+// contiguous ranges; partial accumulators meet in LDS ((W - 1) x 8 KiB, dynamic) and wavefront 0 finishes the block.
+template <int W, bool FAST>
+__global__ __launch_bounds__(64 * W) void solve_level_split(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx,
+                                                             double *S, int64_t lds, int nrhs, int nchunks)
+{
+    extern __shared__ double red[];  // [W - 1][16][64]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t = blockIdx.x / nchunks;
+    const int cw = (blockIdx.x - t * nchunks) * 64;
+    const BlockHeader h = B.hdr[B.task_ptr[task_begin + t]];
+    const PanelCtx c = make_ctx<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane);
+    const int32_t *ids = B.src_idx + h.src_off;
+    const int nst = h.nsrc >> 4;
+    f64x4 acc[4];
+    if (w == 0) {
+        panel_load_rows<FAST>(acc, ids + 16, c);
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+    panel_accumulate<FAST>(acc, c, (nst * w) / W, (nst * (w + 1)) / W);
+    if (w > 0) {
+        double *mine = red + (size_t)(w - 1) * 1024 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mine[(nt * 4 + s) * 64] = acc[nt][s];
+    }
+    __syncthreads();
+    if (w == 0) {
+        for (int o = 0; o < W - 1; ++o) {
+            const double *theirs = red + (size_t)o * 1024 + lane;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[nt][s] += theirs[(nt * 4 + s) * 64];
+        }
+        panel_finish<FAST>(acc, h, ids, c, X, S);
     }
 }
 

@@ -96,8 +96,8 @@ struct BlockedProgram {
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
     struct Level {
-        i64 task_begin;
-        int ntasks;
+        i64 task_begin[3];  // by split class: 1, 4, 16 wavefronts per (block, 64 columns)
+        int ntasks[3];
         i64 cluster_begin;
         int nclusters;
     };

@@ -113,9 +113,15 @@ void TriSolver::build_blocked()
     D.levels.clear();
     D.launches = 0;
     for (i64 l = 0; l < D.nlevels; ++l) {
-        BlockedProgram::Level lv{P.level_ptr[l], (int)(P.level_ptr[l + 1] - P.level_ptr[l]), P.cluster_level_ptr[l],
-                                 (int)(P.cluster_level_ptr[l + 1] - P.cluster_level_ptr[l])};
-        D.launches += (lv.ntasks > 0) + (lv.nclusters > 0);
+        BlockedProgram::Level lv;
+        for (int c = 0; c < 3; ++c) {
+            lv.task_begin[c] = P.level_class_ptr[3 * l + c];
+            lv.ntasks[c] = (int)(P.level_class_ptr[3 * l + c + 1] - P.level_class_ptr[3 * l + c]);
+            D.launches += lv.ntasks[c] > 0;
+        }
+        lv.cluster_begin = P.cluster_level_ptr[l];
+        lv.nclusters = (int)(P.cluster_level_ptr[l + 1] - P.cluster_level_ptr[l]);
+        D.launches += lv.nclusters > 0;
         D.levels.push_back(lv);
     }
     D.task_ptr.upload(P.task_ptr);
@@ -126,6 +132,8 @@ void TriSolver::build_blocked()
     D.clusters.upload(P.clusters);
     D.cluster_ids.upload(P.cluster_ids);
     D.groups.upload(P.groups);
+    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_level_split<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8192));
+    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_level_split<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8192));
     if ((size_t)D.cluster_slots * 512 + 1024 > 64 * 1024)
         RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     D.cluster_slots * 512 + 1024));
@@ -144,15 +152,40 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     const int wpb = 4;
     // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
     const int nchunks = (int)((nrhs + 63) / 64);
+    // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
+    const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)scratch_.get() % 16) == 0;
     for (const auto &lv : P.levels) {
         if (lv.nclusters)  // clusters and block tasks of one level are independent of each other
             hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * nchunks)), dim3(64),
-                               (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs, P.cluster_slots);
-        if (lv.ntasks) {
-            const i64 waves = (i64)lv.ntasks * nchunks;
+                               (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs,
+                               P.cluster_slots);
+        if (lv.ntasks[0]) {
+            const i64 waves = (i64)lv.ntasks[0] * nchunks;
             const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
-            hipLaunchKernelGGL(dev::solve_level_blocked, grid, block, 0, stream, A, lv.task_begin, lv.ntasks, X, ld, scratch_.get(),
-                               nrhs, (int)nrhs, nchunks);
+            if (fast)
+                hipLaunchKernelGGL(dev::solve_level_blocked<true>, grid, block, 0, stream, A, lv.task_begin[0], lv.ntasks[0], X, ld,
+                                   scratch_.get(), nrhs, (int)nrhs, nchunks);
+            else
+                hipLaunchKernelGGL(dev::solve_level_blocked<false>, grid, block, 0, stream, A, lv.task_begin[0], lv.ntasks[0], X, ld,
+                                   scratch_.get(), nrhs, (int)nrhs, nchunks);
+        }
+        if (lv.ntasks[1]) {
+            const dim3 grid((unsigned)((i64)lv.ntasks[1] * nchunks)), block(64 * 4);
+            if (fast)
+                hipLaunchKernelGGL((dev::solve_level_split<4, true>), grid, block, 3 * 8192, stream, A, lv.task_begin[1], lv.ntasks[1], X,
+                                   ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+            else
+                hipLaunchKernelGGL((dev::solve_level_split<4, false>), grid, block, 3 * 8192, stream, A, lv.task_begin[1], lv.ntasks[1], X,
+                                   ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+        }
+        if (lv.ntasks[2]) {
+            const dim3 grid((unsigned)((i64)lv.ntasks[2] * nchunks)), block(64 * 16);
+            if (fast)
+                hipLaunchKernelGGL((dev::solve_level_split<16, true>), grid, block, 15 * 8192, stream, A, lv.task_begin[2], lv.ntasks[2],
+                                   X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+            else
+                hipLaunchKernelGGL((dev::solve_level_split<16, false>), grid, block, 15 * 8192, stream, A, lv.task_begin[2], lv.ntasks[2],
+                                   X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
         }
     }
     RSP_HIP(hipGetLastError());

@@ -378,7 +378,9 @@ class Builder {
         }
         // a wavefront runs at most max_blocks_ dependent blocks back to back: every block costs a chain of dependent
         // global loads (header, ids, rows), so longer tasks stretch the level they run in
-        const bool fits = cur_task_ >= 0 && task_nblk_[cur_task_] < max_blocks_;
+        // blocks with many sources are split over the wavefronts of a workgroup on the device: a task of their own
+        const bool wide = class_of(rows) == 16 && distinct_sources(src_) >= kSplitSources;
+        const bool fits = !wide && cur_task_ >= 0 && task_nblk_[cur_task_] < max_blocks_;
         i64 level;
         if (fits && need <= task_level_[cur_task_] && (chained || need == task_level_[cur_task_])) {
             level = task_level_[cur_task_];
@@ -398,6 +400,64 @@ class Builder {
             avail_[row_at(t)] = (int32_t)level;
             task_of_[row_at(t)] = (int32_t)cur_task_;
         }
+        if (wide) close_task();  // nothing is appended to it
+    }
+
+    i64 distinct_sources(const std::vector<Triple> &src)
+    {
+        ++stamp_id_;
+        i64 k = 0;
+        for (const Triple &x : src) {
+            const i64 key = x.pos;  // positions are unique per source row
+            if (stamp_[key] != stamp_id_) {
+                stamp_[key] = stamp_id_;
+                ++k;
+            }
+        }
+        return k;
+    }
+
+    // ---- gather into dest with the source list cut into partial sums of at most kMaxBlockSources sources ----------
+    // src triples: pos = ordinal understood by id_of.  Every block is its own task.  Returns the level at which dest
+    // is complete.
+    template <class IdOf>
+    i64 emit_gather(int rows, const int32_t *dest, const int32_t *init, std::vector<Triple> &src, IdOf id_of, i64 level)
+    {
+        std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
+        i64 ns = 0;
+        for (size_t k = 0; k < src.size(); ++k) ns += (k == 0 || src[k].pos != src[k - 1].pos);
+        if (ns <= kMaxBlockSources) {
+            push_block(rows, dest, init, src, id_of, nullptr, level, true);
+            return level;
+        }
+        const i64 parts = (ns + kMaxBlockSources - 1) / kMaxBlockSources;
+        const i64 per = (ns + parts - 1) / parts;
+        std::vector<int32_t> pdest((size_t)parts * rows);
+        std::vector<Triple> chunk;
+        size_t k = 0;
+        for (i64 p = 0; p < parts; ++p) {
+            chunk.clear();
+            i64 taken = 0;
+            while (k < src.size()) {
+                const bool new_src = (chunk.empty() || src[k].pos != chunk.back().pos);
+                if (new_src && taken == per) break;
+                taken += new_src;
+                chunk.push_back(src[k++]);
+            }
+            int32_t none[16];
+            for (int r = 0; r < rows; ++r) {
+                pdest[(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
+                none[r] = kNone;
+            }
+            push_block(rows, &pdest[(size_t)p * rows], p == 0 ? init : none, chunk, id_of, nullptr, level, true);
+        }
+        // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial)
+        std::vector<Triple> comb;
+        for (i64 p = 1; p < parts; ++p)
+            for (int r = 0; r < rows; ++r) comb.push_back(Triple{(int32_t)((p - 1) * rows + r), r, -1.0});
+        const int32_t *p1 = pdest.data() + rows;
+        push_block(rows, dest, pdest.data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, level + 1, true);
+        return level + 1;
     }
 
     // ---- long dense chains: Y = X_J - L[J,ext] X_ext ; X_J = M^-1 Y ------------------------------------------
@@ -452,10 +512,11 @@ class Builder {
                     need = std::max<i64>(need, avail_[s] + 1);
                 }
             }
-            push_block(rows, dest, init, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, nullptr, need, true);
-            ready = std::max(ready, need);
+            const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, need);
+            ready = std::max(ready, done);
         }
         // phase B: X_J = Minv * Y, all groups independent
+        i64 final_level = ready + 1;
         for (i64 a = t0; a < t1; a += 16) {
             const i64 b = std::min(a + 16, t1);
             const int rows = (int)(b - a);
@@ -468,10 +529,11 @@ class Builder {
                 const double *Mi = &Minv[(size_t)(t - t0) * w];
                 for (i64 u = 0; u <= t - t0; ++u) src_.push_back(Triple{(int32_t)u, slot, -Mi[u]});
             }
-            push_block(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, nullptr, ready + 1, true);
+            const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
+            final_level = std::max(final_level, done);
         }
         for (i64 t = t0; t < t1; ++t) {
-            avail_[row_at(t)] = (int32_t)(ready + 1);
+            avail_[row_at(t)] = (int32_t)final_level;
             task_of_[row_at(t)] = -2;  // never "chained" to a running task
         }
         close_task();
@@ -500,11 +562,19 @@ class Builder {
             for (i64 c = 0; c < nclusters; ++c)
                 if (!read[emit_order_[c]]) cluster_level_[c] = (int32_t)(nlev - 1);
         }
+        // inside a level, tasks are grouped by split class (how many wavefronts share one block)
+        auto split_class = [&](i64 t) {
+            const BlockHeader &h = P_.hdr[task_first_blk_[t]];
+            if (task_nblk_[t] != 1 || h.rc != 16 || h.nsrc < kSplitSources) return 0;
+            return h.nsrc > 4 * kSplitSources ? 2 : 1;
+        };
+        P_.level_class_ptr.assign(3 * nlev + 1, 0);
+        for (i64 t = 0; t < ntasks; ++t) P_.level_class_ptr[3 * task_level_[t] + split_class(t) + 1]++;
+        for (i64 k = 0; k < 3 * nlev; ++k) P_.level_class_ptr[k + 1] += P_.level_class_ptr[k];
         P_.level_ptr.assign(nlev + 1, 0);
-        for (int32_t l : task_level_) P_.level_ptr[l + 1]++;
-        for (i64 l = 0; l < nlev; ++l) P_.level_ptr[l + 1] += P_.level_ptr[l];
-        std::vector<i64> fill(P_.level_ptr.begin(), P_.level_ptr.end() - 1), order(ntasks);
-        for (i64 t = 0; t < ntasks; ++t) order[fill[task_level_[t]]++] = t;
+        for (i64 l = 0; l <= nlev; ++l) P_.level_ptr[l] = P_.level_class_ptr[3 * l];
+        std::vector<i64> fill(P_.level_class_ptr.begin(), P_.level_class_ptr.end() - 1), order(ntasks);
+        for (i64 t = 0; t < ntasks; ++t) order[fill[3 * task_level_[t] + split_class(t)]++] = t;
         std::vector<BlockHeader> hdr(P_.hdr.size());
         P_.task_ptr.assign(ntasks + 1, 0);
         i64 at = 0;
