@@ -3,13 +3,14 @@
 // One wavefront owns (task, 64 right-hand sides) and executes the task's blocks in order.  A block computes
 //     acc[r] = init[r] - sum_e coef[e][r] * src[e]      (+ the block's own small triangular solve)
 // for up to 16 unknowns r at once, so every gathered source row is used for all unknowns of the block.
-// The kernel is latency-, not bandwidth-bound unless the dependent loads are kept short and deep, hence:
-//   * one 32-byte header per block (a single scalar load) instead of one load per field;
-//   * source ids are fetched 64 (vector path: 16) at a time with ONE coalesced vector load and handed out with
-//     ds_bpermute / v_readlane, so the gathers of a whole batch can be issued back to back;
-//   * coefficients are read as coalesced vector loads (MFMA A operands, or broadcast by v_readlane);
-//   * 16-unknown blocks run on the matrix cores (v_mfma_f64_16x16x4_f64), which keeps the register
-//     footprint small enough for 5 wavefronts per SIMD.
+// Under load a dependent global round trip costs microseconds, so every path below is written as THREE of them:
+//   1. the 32-byte block header (one scalar load),
+//   2. everything the header points to that is an index or a coefficient: destination / initial-value ids, the ids
+//      and coefficients of the first sources, the block's triangle -- all issued together,
+//   3. the rows themselves (initial values and first sources together),
+// after which long source lists run as a software pipeline (loads of the next stage in flight during the arithmetic).
+// 16-unknown blocks run on the matrix cores (v_mfma_f64_16x16x4_f64); blocks of 1, 2 or 4 unknowns in per-lane registers.
+// The host pads src_idx and coef by one wavefront's worth of entries, so clamped speculative fetches stay in bounds.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,20 +49,22 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const BlockAr
 {
     const int32_t *ids = B.src_idx + h.src_off;
     const double *cf = B.coef + h.coef_off;
-    // dest / init ids: lanes 0..2RC-1 load them at once
+    const int32_t *sidx = ids + 2 * RC;
+    constexpr int SB = 16;  // sources per batch: 16 ids and 16*RC <= 64 coefficients, one vector load each
+    // round trip 2: dest / init ids (lanes 0..2RC-1), ids + coefficients of the first batch, the triangle
     const int32_t hid = ids[lane < 2 * RC ? lane : 0];
+    int nb = min(SB, h.nsrc);
+    int32_t idv = sidx[lane < nb ? lane : 0];
+    double cv = cf[lane < nb * RC ? lane : 0];
+    const double tv = cf[(int64_t)h.nsrc * RC + (lane < RC * RC ? lane : 0)];  // padded pool: in bounds without a triangle
+    // round trip 3: initial values and the rows of the first batch
     double acc[RC];
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
         const int32_t id = __builtin_amdgcn_readlane(hid, RC + r);
         acc[r] = (id != RSP_NONE && live) ? row_ptr(id, X, ldx, S, lds)[col] : 0.0;
     }
-    const int32_t *sidx = ids + 2 * RC;
-    constexpr int SB = 16;  // sources per batch: 16 ids and 16*RC <= 64 coefficients, one vector load each
     for (int e0 = 0; e0 < h.nsrc; e0 += SB) {
-        const int nb = min(SB, h.nsrc - e0);
-        const int32_t idv = sidx[e0 + (lane < nb ? lane : 0)];
-        const double cv = cf[(int64_t)e0 * RC + (lane < nb * RC ? lane : 0)];
         double x[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -72,6 +75,10 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const BlockAr
                 x[u] = 0.0;
             }
         }
+        // ids and coefficients of the next batch travel while this one is multiplied
+        const int nb_next = min(SB, h.nsrc - e0 - SB);
+        const int32_t idv_next = sidx[e0 + SB + (lane < nb_next ? lane : 0)];
+        const double cv_next = cf[(int64_t)(e0 + SB) * RC + (lane < nb_next * RC ? lane : 0)];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             if (u < nb) {
@@ -79,9 +86,11 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const BlockAr
                 for (int r = 0; r < RC; ++r) acc[r] -= readlane_f64(cv, u * RC + r) * x[u];
             }
         }
+        nb = nb_next;
+        idv = idv_next;
+        cv = cv_next;
     }
     if (h.has_tri) {
-        const double tv = cf[(int64_t)h.nsrc * RC + (lane < RC * RC ? lane : 0)];
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
 #pragma unroll
@@ -162,34 +171,31 @@ __device__ __forceinline__ void mfma_stage(f64x4 (&acc)[4], const Stage &R)
     }
 }
 
-// acc -= coef[st_begin*16 .. st_end*16) * sources
-template <bool FAST>
-__device__ __forceinline__ void panel_accumulate(f64x4 (&acc)[4], const PanelCtx &c, int st_begin, int st_end)
-{
-    if (st_begin >= st_end) return;
-    const int last = st_end - 1;
-    int32_t idA[4], idB[4];
-    Stage A, B;
-    load_ids(idA, c, st_begin);
-    load_ids(idB, c, min(st_begin + 1, last));
-    load_stage<FAST>(A, idA, c, st_begin);
-    for (int s = st_begin; s < st_end; s += 2) {
-        load_stage<FAST>(B, idB, c, min(s + 1, last));
-        load_ids(idA, c, min(s + 2, last));
-        mfma_stage(acc, A);
-        load_stage<FAST>(A, idA, c, min(s + 2, last));
-        load_ids(idB, c, min(s + 3, last));
-        if (s + 1 < st_end) mfma_stage(acc, B);
-    }
-}
+// ids and triangle of a block, fetched in the same round trip as the first source ids
+struct PanelIds {
+    int32_t init[4], dest[4];  // unknown 4s + g for s = 0..3
+    double tinv[4];            // A operands of the inverse triangle
+};
 
-// rows of the block -> acc (register s <- unknown 4s + g); ids16 = 16 ids, kNone = zero
-template <bool FAST>
-__device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t *ids16, const PanelCtx &c)
+__device__ __forceinline__ void load_panel_ids(PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c, bool lead)
 {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int32_t id = ids16[4 * s + c.g];
+        P.dest[s] = ids[4 * s + c.g];
+        P.init[s] = lead ? ids[16 + 4 * s + c.g] : RSP_NONE;
+    }
+    const double *tinv = c.cf + (int64_t)h.nsrc * 16;  // padded pool: in bounds without a triangle
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P.tinv[k] = tinv[k * 64 + c.lane];
+}
+
+// rows of the block -> acc (register s <- unknown 4s + g); kNone = zero
+template <bool FAST>
+__device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t (&id4)[4], const PanelCtx &c)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int32_t id = id4[s];
         double v[4] = {0.0, 0.0, 0.0, 0.0};
         if (id != RSP_NONE) {
             const double *p = row_ptr(id, c.X, c.ldx, c.S, c.lds) + c.cb;
@@ -209,27 +215,51 @@ __device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t *
     }
 }
 
+// acc = init rows - coef[st_begin*16 .. st_end*16) * sources.  `lead`: this wavefront loads the initial values.
+template <bool FAST>
+__device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c,
+                                             int st_begin, int st_end, bool lead)
+{
+    const int last = st_end - 1;
+    const bool any = st_begin < st_end;  // wave-uniform; a block may have no sources at all
+    int32_t idA[4], idB[4];
+    Stage A, B;
+    // round trip 2
+    load_panel_ids(P, ids, h, c, lead);
+    if (any) {
+        load_ids(idA, c, st_begin);
+        load_ids(idB, c, min(st_begin + 1, last));
+    }
+    // round trip 3
+    panel_load_rows<FAST>(acc, P.init, c);
+    if (!any) return;
+    load_stage<FAST>(A, idA, c, st_begin);
+    for (int s = st_begin; s < st_end; s += 2) {
+        load_stage<FAST>(B, idB, c, min(s + 1, last));
+        load_ids(idA, c, min(s + 2, last));
+        mfma_stage(acc, A);
+        load_stage<FAST>(A, idA, c, min(s + 2, last));
+        load_ids(idB, c, min(s + 3, last));
+        if (s + 1 < st_end) mfma_stage(acc, B);
+    }
+}
+
 // in-block triangle (as its inverse) and the store of the 16 unknowns
 template <bool FAST>
-__device__ __forceinline__ void panel_finish(f64x4 (&acc)[4], const BlockHeader h, const int32_t *ids16, const PanelCtx &c, double *X,
-                                             double *S)
+__device__ __forceinline__ void panel_finish(f64x4 (&acc)[4], const PanelIds &P, const BlockHeader h, const PanelCtx &c, double *X, double *S)
 {
     if (h.has_tri) {
-        const double *tinv = c.cf + (int64_t)h.nsrc * 16;  // 4 x 64 doubles in A-operand order
-        double a4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a4[k] = tinv[k * 64 + c.lane];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f64x4 r = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[k], acc[nt][k], r, 0, 0, 0);
+            for (int k = 0; k < 4; ++k) r = __builtin_amdgcn_mfma_f64_16x16x4f64(P.tinv[k], acc[nt][k], r, 0, 0, 0);
             acc[nt] = r;
         }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int32_t id = ids16[4 * s + c.g];
+        const int32_t id = P.dest[s];
         if (id != RSP_NONE) {
             double *p = const_cast<double *>(row_ptr(id, X, c.ldx, S, c.lds)) + c.cb;
             if (FAST) {
@@ -246,7 +276,6 @@ __device__ __forceinline__ void panel_finish(f64x4 (&acc)[4], const BlockHeader 
     }
 }
 
-template <bool FAST>
 __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArrays &B, const double *X, int64_t ldx, const double *S,
                                              int64_t lds, int cw, int nrhs, int lane)
 {
@@ -269,12 +298,11 @@ template <bool FAST>
 __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockArrays &B, double *X, int64_t ldx, double *S, int64_t lds,
                                                int cw, int nrhs, int lane)
 {
-    const PanelCtx c = make_ctx<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane);
-    const int32_t *ids = B.src_idx + h.src_off;  // 16 dest ids, 16 init ids
+    const PanelCtx c = make_ctx(h, B, X, ldx, S, lds, cw, nrhs, lane);
+    PanelIds P;
     f64x4 acc[4];
-    panel_load_rows<FAST>(acc, ids + 16, c);
-    panel_accumulate<FAST>(acc, c, 0, h.nsrc >> 4);
-    panel_finish<FAST>(acc, h, ids, c, X, S);
+    panel_gather<FAST>(acc, P, B.src_idx + h.src_off, h, c, 0, h.nsrc >> 4, true);
+    panel_finish<FAST>(acc, P, h, c, X, S);
 }
 
 // one wavefront per (task, 64 columns); the blocks of a task run in order
@@ -302,29 +330,24 @@ __global__ __launch_bounds__(256) void solve_level_blocked(BlockArrays B, int64_
     }
 }
 
-// W wavefronts per (task, 64 columns): the task is ONE matrix-core block whose stages are dealt to the wavefronts in
-// contiguous ranges; partial accumulators meet in LDS ((W - 1) x 8 KiB, dynamic) and wavefront 0 finishes the block.
+// W wavefronts per (block, 64 columns): the stages of ONE matrix-core block are dealt to the wavefronts in contiguous
+// ranges; partial accumulators meet in LDS ((W - 1) x 8 KiB, dynamic) and wavefront 0 finishes the block.
+// The tasks of a split class hold one block each, so block t of the launch is block_begin + t: no task_ptr round trip.
 template <int W, bool FAST>
-__global__ __launch_bounds__(64 * W) void solve_level_split(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx,
-                                                             double *S, int64_t lds, int nrhs, int nchunks)
+__global__ __launch_bounds__(64 * W) void solve_level_split(BlockArrays B, int64_t block_begin, double *X, int64_t ldx, double *S,
+                                                             int64_t lds, int nrhs, int nchunks)
 {
     extern __shared__ double red[];  // [W - 1][16][64]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t = blockIdx.x / nchunks;
     const int cw = (blockIdx.x - t * nchunks) * 64;
-    const BlockHeader h = B.hdr[B.task_ptr[task_begin + t]];
-    const PanelCtx c = make_ctx<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane);
-    const int32_t *ids = B.src_idx + h.src_off;
+    const BlockHeader h = B.hdr[block_begin + t];
+    const PanelCtx c = make_ctx(h, B, X, ldx, S, lds, cw, nrhs, lane);
     const int nst = h.nsrc >> 4;
+    PanelIds P;
     f64x4 acc[4];
-    if (w == 0) {
-        panel_load_rows<FAST>(acc, ids + 16, c);
-    } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = f64x4{0.0, 0.0, 0.0, 0.0};
-    }
-    panel_accumulate<FAST>(acc, c, (nst * w) / W, (nst * (w + 1)) / W);
+    panel_gather<FAST>(acc, P, B.src_idx + h.src_off, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
     if (w > 0) {
         double *mine = red + (size_t)(w - 1) * 1024 + lane;
 #pragma unroll
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(64 * W) void solve_level_split(BlockArrays B, int64
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[nt][s] += theirs[(nt * 4 + s) * 64];
         }
-        panel_finish<FAST>(acc, h, ids, c, X, S);
+        panel_finish<FAST>(acc, P, h, c, X, S);
     }
 }
 

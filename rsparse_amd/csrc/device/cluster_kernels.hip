@@ -3,8 +3,9 @@
 // One wavefront owns (cluster, 64 right-hand sides).  A cluster is a set of small dependency subtrees: dozens of
 // unknowns with a handful of entries each, every one depending on the previous ones.  Solved through global memory
 // that is one HBM/L2 round trip per unknown; here the wavefront
-//   1. copies the rows of X the cluster touches (external sources, then its own unknowns) into LDS slots,
-//      16 coalesced 512-byte row loads in flight at a time,
+//   1. copies the rows of X the cluster touches (external sources, then its own unknowns) into LDS slots.  Under load
+//      a dependent global round trip costs microseconds, so the kernel makes exactly three of them before it computes:
+//      header, then ids + first records, then all rows (up to 32 coalesced 512-byte row loads in flight),
 //   2. runs the whole dependent chain out of LDS.  The arithmetic arrives as 64-byte group records (four
 //      multiply-subtracts each): 16 records (1 KiB) per coalesced vector load, fetched one block ahead of their use
 //      and parked in a 1 KiB LDS ring, from which every lane reads the current record at the same address
@@ -71,7 +72,7 @@ __device__ __forceinline__ void run_group(const GroupRegs &r, double *xs_lane, d
 
 // one 64-thread workgroup (= one wavefront) per (cluster, 64 columns); dynamic LDS = slots * 512 + 1024 bytes
 __global__ __launch_bounds__(64) void solve_clusters(ClusterArrays C, int64_t cluster_begin, int nchunks, double *__restrict__ X,
-                                                     int64_t ldx, int nrhs, int slots)
+                                                     int64_t ldx, int nrhs, int slots, int mode)
 {
     extern __shared__ double xs[];
     v4i *ring = reinterpret_cast<v4i *>(xs + (size_t)slots * 64);  // 16 group records
@@ -86,27 +87,29 @@ __global__ __launch_bounds__(64) void solve_clusters(ClusterArrays C, int64_t cl
     const v4i *gsrc = reinterpret_cast<const v4i *>(C.groups + h.grp_off);
     const int ng = h.ngroups, nq = 4 * ng;
 
-    v4i blk = gsrc[min(lane, nq - 1)];  // the first 16 records travel while the rows are being copied in
+    // ONE round trip for everything the header points to: the first 16 records and the row id of every slot
+    // (lane s holds the id of slot s; the builder keeps clusters within 64 slots)
+    v4i blk = gsrc[min(lane, nq - 1)];
+    const int32_t idv = ids[min(lane, nslots - 1)];
 
-    for (int s0 = 0; s0 < nslots; s0 += 16) {
-        const int nb = min(16, nslots - s0);
-        const int32_t idv = ids[s0 + (lane < nb ? lane : 0)];
-        double v[16];
+    // ONE more for the rows themselves: up to 32 coalesced 512-byte row loads in flight per wavefront
+    for (int s0 = 0; s0 < nslots; s0 += 32) {
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (u < nb) {  // wave-uniform
-                const int64_t id = __builtin_amdgcn_readlane(idv, u);
+        for (int u = 0; u < 32; ++u) {
+            if (s0 + u < nslots) {  // wave-uniform
+                const int64_t id = __builtin_amdgcn_readlane(idv, s0 + u);
                 v[u] = live ? X[id * ldx + col] : 0.0;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (u < nb) xs[(s0 + u) * 64 + lane] = v[u];
+        for (int u = 0; u < 32; ++u)
+            if (s0 + u < nslots) xs[(s0 + u) * 64 + lane] = v[u];
     }
 
     double *xs_lane = xs + lane;
     double acc = 0.0;
-    for (int b0 = 0; b0 < ng; b0 += 16) {
+    for (int b0 = 0; b0 < (mode == 1 ? 0 : ng); b0 += 16) {
         ring[lane] = blk;
         blk = gsrc[min(4 * (b0 + 16) + lane, nq - 1)];  // next block: in flight while this one is executed
         const int nb = min(16, ng - b0);
@@ -118,17 +121,10 @@ __global__ __launch_bounds__(64) void solve_clusters(ClusterArrays C, int64_t cl
         }
     }
 
-    for (int s0 = h.n_ext; s0 < nslots; s0 += 16) {
-        const int nb = min(16, nslots - s0);
-        // every lane takes part in the id fetch (lane u holds the id of slot s0 + u), also those without a column
-        const int32_t idv = ids[s0 + (lane < nb ? lane : 0)];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (u < nb) {
-                const int64_t id = __builtin_amdgcn_readlane(idv, u);
-                if (live) X[id * ldx + col] = xs[(s0 + u) * 64 + lane];
-            }
-        }
+    // the ids are still in registers: the write-back costs no further round trip
+    for (int s = h.n_ext; s < nslots; ++s) {
+        const int64_t id = __builtin_amdgcn_readlane(idv, s);
+        if (live) X[id * ldx + col] = xs[s * 64 + lane];
     }
 }
 

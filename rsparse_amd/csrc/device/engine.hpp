@@ -96,8 +96,9 @@ struct BlockedProgram {
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
     struct Level {
-        i64 task_begin[3];  // by split class: 1, 4, 16 wavefronts per (block, 64 columns)
+        i64 task_begin[3];  // by split class: 1, 4, 8 wavefronts per (block, 64 columns)
         int ntasks[3];
+        i64 block_begin[3];  // first block of each class (split classes: one block per task)
         i64 cluster_begin;
         int nclusters;
     };

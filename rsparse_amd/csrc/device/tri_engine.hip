@@ -117,6 +117,7 @@ void TriSolver::build_blocked()
         for (int c = 0; c < 3; ++c) {
             lv.task_begin[c] = P.level_class_ptr[3 * l + c];
             lv.ntasks[c] = (int)(P.level_class_ptr[3 * l + c + 1] - P.level_class_ptr[3 * l + c]);
+            lv.block_begin[c] = P.task_ptr[lv.task_begin[c]];
             D.launches += lv.ntasks[c] > 0;
         }
         lv.cluster_begin = P.cluster_level_ptr[l];
@@ -132,8 +133,6 @@ void TriSolver::build_blocked()
     D.clusters.upload(P.clusters);
     D.cluster_ids.upload(P.cluster_ids);
     D.groups.upload(P.groups);
-    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_level_split<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8192));
-    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_level_split<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 15 * 8192));
     if ((size_t)D.cluster_slots * 512 + 1024 > 64 * 1024)
         RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     D.cluster_slots * 512 + 1024));
@@ -158,7 +157,7 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
         if (lv.nclusters)  // clusters and block tasks of one level are independent of each other
             hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * nchunks)), dim3(64),
                                (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs,
-                               P.cluster_slots);
+                               P.cluster_slots, (int)env_or("RSP_CLUSTER_MODE", 0));
         if (lv.ntasks[0]) {
             const i64 waves = (i64)lv.ntasks[0] * nchunks;
             const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
@@ -172,19 +171,19 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
         if (lv.ntasks[1]) {
             const dim3 grid((unsigned)((i64)lv.ntasks[1] * nchunks)), block(64 * 4);
             if (fast)
-                hipLaunchKernelGGL((dev::solve_level_split<4, true>), grid, block, 3 * 8192, stream, A, lv.task_begin[1], lv.ntasks[1], X,
+                hipLaunchKernelGGL((dev::solve_level_split<4, true>), grid, block, 3 * 8192, stream, A, lv.block_begin[1], X,
                                    ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
             else
-                hipLaunchKernelGGL((dev::solve_level_split<4, false>), grid, block, 3 * 8192, stream, A, lv.task_begin[1], lv.ntasks[1], X,
+                hipLaunchKernelGGL((dev::solve_level_split<4, false>), grid, block, 3 * 8192, stream, A, lv.block_begin[1], X,
                                    ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
         }
         if (lv.ntasks[2]) {
-            const dim3 grid((unsigned)((i64)lv.ntasks[2] * nchunks)), block(64 * 16);
+            const dim3 grid((unsigned)((i64)lv.ntasks[2] * nchunks)), block(64 * 8);
             if (fast)
-                hipLaunchKernelGGL((dev::solve_level_split<16, true>), grid, block, 15 * 8192, stream, A, lv.task_begin[2], lv.ntasks[2],
+                hipLaunchKernelGGL((dev::solve_level_split<8, true>), grid, block, 7 * 8192, stream, A, lv.block_begin[2],
                                    X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
             else
-                hipLaunchKernelGGL((dev::solve_level_split<16, false>), grid, block, 15 * 8192, stream, A, lv.task_begin[2], lv.ntasks[2],
+                hipLaunchKernelGGL((dev::solve_level_split<8, false>), grid, block, 7 * 8192, stream, A, lv.block_begin[2],
                                    X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
         }
     }

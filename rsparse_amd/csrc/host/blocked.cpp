@@ -29,7 +29,7 @@ struct Triple {
 class Builder {
    public:
     Builder(const GatherForm &G, i64 max_blocks, int slots)
-        : G_(G), n_(G.n), max_blocks_(std::max<i64>(1, max_blocks)), slots_(slots)
+        : G_(G), n_(G.n), max_blocks_(std::max<i64>(1, max_blocks)), slots_(std::min(slots, 64))  // one id per lane
     {
         avail_.assign(n_, 0);
         task_of_.assign(n_, -1);
@@ -245,8 +245,11 @@ class Builder {
     i64 push_block(int rows, const int32_t *dest, const int32_t *init, std::vector<Triple> &src, IdOf id_of, const double *tri,
                    i64 level, bool own_task)
     {
-        const int rc = class_of(rows);
         std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
+        i64 distinct = 0;
+        for (size_t k = 0; k < src.size(); ++k) distinct += (k == 0 || src[k].pos != src[k - 1].pos);
+        // long source lists always take the matrix-core path: it is pipelined and can be split over wavefronts
+        const int rc = distinct >= kSplitSources ? 16 : class_of(rows);
         const i64 b = (i64)P_.hdr.size();
         BlockHeader h{rc, 0, tri ? 1 : 0, 0, (i64)P_.src_idx.size(), (i64)P_.coef.size()};
         for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? dest[r] : kNone);
@@ -379,7 +382,7 @@ class Builder {
         // a wavefront runs at most max_blocks_ dependent blocks back to back: every block costs a chain of dependent
         // global loads (header, ids, rows), so longer tasks stretch the level they run in
         // blocks with many sources are split over the wavefronts of a workgroup on the device: a task of their own
-        const bool wide = class_of(rows) == 16 && distinct_sources(src_) >= kSplitSources;
+        const bool wide = distinct_sources(src_) >= kSplitSources;
         const bool fits = !wide && cur_task_ >= 0 && task_nblk_[cur_task_] < max_blocks_;
         i64 level;
         if (fits && need <= task_level_[cur_task_] && (chained || need == task_level_[cur_task_])) {
@@ -585,6 +588,9 @@ class Builder {
         }
         P_.task_ptr[ntasks] = at;
         P_.hdr.swap(hdr);
+        // the kernels fetch ids, coefficients and the triangle speculatively (clamped lane offsets): keep those in bounds
+        P_.src_idx.resize(P_.src_idx.size() + 128, 0);
+        P_.coef.resize(P_.coef.size() + 320, 0.0);
         // clusters
         P_.cluster_level_ptr.assign(nlev + 1, 0);
         for (int32_t l : cluster_level_) P_.cluster_level_ptr[l + 1]++;

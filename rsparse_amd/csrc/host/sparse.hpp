@@ -169,14 +169,14 @@ struct BlockProgram {
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
     std::vector<i64> level_ptr;      // block tasks of level l
     std::vector<i64> level_class_ptr;  // 3 entries per level: tasks of split class 0 (one wavefront per block and 64
-                                       // columns), 1 (4 wavefronts share the block's sources), 2 (16 wavefronts)
+                                       // columns), 1 (4 wavefronts share the block's sources), 2 (8 wavefronts)
     std::vector<i64> cluster_level_ptr;  // clusters of level l (same level numbering)
     i64 scratch_rows = 0;
     i64 big_chains = 0, inverted_rows = 0, padded_entries = 0, cluster_rows = 0, cluster_entries = 0;
 };
 constexpr i64 kBigChain = 32;        // chains longer than this are replaced by their inverse
 constexpr i64 kSplitSources = 64;    // matrix-core blocks with at least this many sources are split over 4 wavefronts,
-                                     // with more than 4x this over 16
+                                     // with more than 4x this over 8
 constexpr i64 kMaxBlockSources = 1024;  // longer source lists become partial sums (scratch rows) plus a combine block
 constexpr int kClusterSlots = 48;    // default LDS slots per cluster (24 KB per wavefront at 64 right-hand sides)
 constexpr i64 kTaskBlocks = 2;       // default number of dependent blocks one wavefront runs back to back
