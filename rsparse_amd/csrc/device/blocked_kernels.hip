@@ -305,21 +305,33 @@ __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockA
     panel_finish<FAST>(acc, P, h, c, X, S);
 }
 
-// one wavefront per (task, 64 columns); the blocks of a task run in order
+// ---- one launch per level ----------------------------------------------------------------------------------------
+// A level holds block tasks of three split classes (host/blocked.cpp): 0 = one wavefront per (task, 64 columns),
+// 1 = four wavefronts share the sources of one matrix-core block, 2 = eight wavefronts.  All of them run in ONE
+// launch of 512-thread workgroups; a workgroup's role follows from its index.
+//
+// XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an XCD, speed only), each
+// with its own 4 MiB L2.  Work item i = (blockIdx % 8) * per_xcd + blockIdx / 8, so every XCD walks a CONTIGUOUS
+// range of items; inside the split classes items are ordered (group of 8 blocks, 64-column chunk, block), so the
+// workgroups an XCD runs together are consecutive blocks of one supernode on the SAME columns -- they gather the same
+// rows of X, and all but the first find them in that XCD's L2.
+struct LevelDesc {
+    int64_t task_begin;      // class 0: first task
+    int64_t block_begin[2];  // classes 1, 2: first block (one block per task)
+    int ntasks, nblk[2];
+    int wg0, wg1, wg2;       // workgroups per class
+};
+
+// class 0: the blocks of a task run in order
 template <bool FAST>
-__global__ __launch_bounds__(256) void solve_level_blocked(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx,
-                                                            double *S, int64_t lds, int nrhs, int nchunks)
+__device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task, int chunk, double *X, int64_t ldx, double *S, int64_t lds,
+                                         int nrhs, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const int t = wave / nchunks;
-    if (t >= ntasks) return;
-    const int chunk = wave - t * nchunks;
     const int cw = chunk * 64;
     const int col = cw + lane;
     const bool live = col < nrhs;
-    const int64_t bend = B.task_ptr[task_begin + t + 1];
-    for (int64_t b = B.task_ptr[task_begin + t]; b < bend; ++b) {
+    const int64_t bend = B.task_ptr[task + 1];
+    for (int64_t b = B.task_ptr[task]; b < bend; ++b) {
         const BlockHeader h = B.hdr[b];
         switch (h.rc) {
             case 16: run_block_mfma<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane); break;
@@ -330,33 +342,41 @@ __global__ __launch_bounds__(256) void solve_level_blocked(BlockArrays B, int64_
     }
 }
 
-// W wavefronts per (block, 64 columns): the stages of ONE matrix-core block are dealt to the wavefronts in contiguous
-// ranges; partial accumulators meet in LDS ((W - 1) x 8 KiB, dynamic) and wavefront 0 finishes the block.
-// The tasks of a split class hold one block each, so block t of the launch is block_begin + t: no task_ptr round trip.
-template <int W, bool FAST>
-__global__ __launch_bounds__(64 * W) void solve_level_split(BlockArrays B, int64_t block_begin, double *X, int64_t ldx, double *S,
-                                                             int64_t lds, int nrhs, int nchunks)
+// (group of 8 blocks, chunk, block) order of item q over n blocks
+__device__ __forceinline__ void split_item(int q, int n, int nchunks, int &blk, int &chunk)
 {
-    extern __shared__ double red[];  // [W - 1][16][64]
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int t = blockIdx.x / nchunks;
-    const int cw = (blockIdx.x - t * nchunks) * 64;
-    const BlockHeader h = B.hdr[block_begin + t];
-    const PanelCtx c = make_ctx(h, B, X, ldx, S, lds, cw, nrhs, lane);
-    const int nst = h.nsrc >> 4;
+    const int per_group = 8 * nchunks;
+    const int group = q / per_group, r = q - group * per_group;
+    const int in_group = min(8, n - group * 8);
+    chunk = r / in_group;
+    blk = group * 8 + (r - chunk * in_group);
+}
+
+// W wavefronts (w = 0..W-1) share one matrix-core block: contiguous ranges of its stages each, partial accumulators
+// meet in LDS (red: (W - 1) x 8 KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
+template <int W, bool FAST>
+__device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t block, int chunk, int w, double *red, double *X,
+                                          int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
+{
     PanelIds P;
     f64x4 acc[4];
-    panel_gather<FAST>(acc, P, B.src_idx + h.src_off, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
-    if (w > 0) {
-        double *mine = red + (size_t)(w - 1) * 1024 + lane;
+    BlockHeader h;
+    PanelCtx c;
+    if (valid) {
+        h = B.hdr[block];
+        c = make_ctx(h, B, X, ldx, S, lds, chunk * 64, nrhs, lane);
+        const int nst = h.nsrc >> 4;
+        panel_gather<FAST>(acc, P, B.src_idx + h.src_off, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
+        if (w > 0) {
+            double *mine = red + (size_t)(w - 1) * 1024 + lane;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) mine[(nt * 4 + s) * 64] = acc[nt][s];
+                for (int s = 0; s < 4; ++s) mine[(nt * 4 + s) * 64] = acc[nt][s];
+        }
     }
     __syncthreads();
-    if (w == 0) {
+    if (valid && w == 0) {
         for (int o = 0; o < W - 1; ++o) {
             const double *theirs = red + (size_t)o * 1024 + lane;
 #pragma unroll
@@ -365,6 +385,32 @@ __global__ __launch_bounds__(64 * W) void solve_level_split(BlockArrays B, int64
                 for (int s = 0; s < 4; ++s) acc[nt][s] += theirs[(nt * 4 + s) * 64];
         }
         panel_finish<FAST>(acc, P, h, c, X, S);
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(512) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
+                                                    int nchunks)
+{
+    extern __shared__ double red[];  // 7 x 8 KiB
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..7
+    const int per_xcd = (int)(gridDim.x >> 3);                              // the grid is a multiple of 8 workgroups
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item < L.wg0) {  // 8 (task, chunk) pairs
+        const int pair = item * 8 + w;
+        const int t = pair / nchunks;
+        if (t < L.ntasks) run_task<FAST>(B, L.task_begin + t, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
+    } else if (item < L.wg0 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
+        const int q = (item - L.wg0) * 2 + (w >> 2);
+        const bool valid = q < L.nblk[0] * nchunks;
+        int blk = 0, chunk = 0;
+        if (valid) split_item(q, L.nblk[0], nchunks, blk, chunk);
+        run_split<4, FAST>(B, valid, L.block_begin[0] + blk, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
+    } else if (item < L.wg0 + L.wg1 + L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
+        int blk, chunk;
+        split_item(item - L.wg0 - L.wg1, L.nblk[1], nchunks, blk, chunk);
+        run_split<8, FAST>(B, true, L.block_begin[1] + blk, chunk, w, red, X, ldx, S, lds, nrhs, lane);
     }
 }
 

@@ -118,8 +118,8 @@ void TriSolver::build_blocked()
             lv.task_begin[c] = P.level_class_ptr[3 * l + c];
             lv.ntasks[c] = (int)(P.level_class_ptr[3 * l + c + 1] - P.level_class_ptr[3 * l + c]);
             lv.block_begin[c] = P.task_ptr[lv.task_begin[c]];
-            D.launches += lv.ntasks[c] > 0;
         }
+        D.launches += (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2]) > 0;
         lv.cluster_begin = P.cluster_level_ptr[l];
         lv.nclusters = (int)(P.cluster_level_ptr[l + 1] - P.cluster_level_ptr[l]);
         D.launches += lv.nclusters > 0;
@@ -148,7 +148,6 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     if (P.scratch_rows) scratch_.resize((size_t)P.scratch_rows * (size_t)nrhs);
     const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get()};
     const dev::ClusterArrays C{P.clusters.get(), P.cluster_ids.get(), P.groups.get()};
-    const int wpb = 4;
     // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
     const int nchunks = (int)((nrhs + 63) / 64);
     // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
@@ -158,33 +157,24 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
             hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * nchunks)), dim3(64),
                                (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs,
                                P.cluster_slots, (int)env_or("RSP_CLUSTER_MODE", 0));
-        if (lv.ntasks[0]) {
-            const i64 waves = (i64)lv.ntasks[0] * nchunks;
-            const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
+        if (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2]) {
+            dev::LevelDesc L;
+            L.task_begin = lv.task_begin[0];
+            L.block_begin[0] = lv.block_begin[1];
+            L.block_begin[1] = lv.block_begin[2];
+            L.ntasks = lv.ntasks[0];
+            L.nblk[0] = lv.ntasks[1];
+            L.nblk[1] = lv.ntasks[2];
+            L.wg0 = (int)(((i64)lv.ntasks[0] * nchunks + 7) / 8);
+            L.wg1 = (int)(((i64)lv.ntasks[1] * nchunks + 1) / 2);
+            L.wg2 = (int)((i64)lv.ntasks[2] * nchunks);
+            const unsigned wgs = (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
             if (fast)
-                hipLaunchKernelGGL(dev::solve_level_blocked<true>, grid, block, 0, stream, A, lv.task_begin[0], lv.ntasks[0], X, ld,
-                                   scratch_.get(), nrhs, (int)nrhs, nchunks);
+                hipLaunchKernelGGL(dev::solve_level<true>, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs,
+                                   (int)nrhs, nchunks);
             else
-                hipLaunchKernelGGL(dev::solve_level_blocked<false>, grid, block, 0, stream, A, lv.task_begin[0], lv.ntasks[0], X, ld,
-                                   scratch_.get(), nrhs, (int)nrhs, nchunks);
-        }
-        if (lv.ntasks[1]) {
-            const dim3 grid((unsigned)((i64)lv.ntasks[1] * nchunks)), block(64 * 4);
-            if (fast)
-                hipLaunchKernelGGL((dev::solve_level_split<4, true>), grid, block, 3 * 8192, stream, A, lv.block_begin[1], X,
-                                   ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
-            else
-                hipLaunchKernelGGL((dev::solve_level_split<4, false>), grid, block, 3 * 8192, stream, A, lv.block_begin[1], X,
-                                   ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
-        }
-        if (lv.ntasks[2]) {
-            const dim3 grid((unsigned)((i64)lv.ntasks[2] * nchunks)), block(64 * 8);
-            if (fast)
-                hipLaunchKernelGGL((dev::solve_level_split<8, true>), grid, block, 7 * 8192, stream, A, lv.block_begin[2],
-                                   X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
-            else
-                hipLaunchKernelGGL((dev::solve_level_split<8, false>), grid, block, 7 * 8192, stream, A, lv.block_begin[2],
-                                   X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+                hipLaunchKernelGGL(dev::solve_level<false>, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs,
+                                   (int)nrhs, nchunks);
         }
     }
     RSP_HIP(hipGetLastError());
