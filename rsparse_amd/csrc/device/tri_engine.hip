@@ -1,4 +1,5 @@
 // TriSolver: uploads a triangular factor in execution order and runs the level-scheduled kernels.
+#include <cstdio>
 #include <cstdlib>
 
 #include "engine.hpp"
@@ -125,6 +126,22 @@ void TriSolver::build_blocked()
         D.launches += lv.nclusters > 0;
         D.levels.push_back(lv);
     }
+    if (getenv("RSP_DUMP_LEVELS")) {  // per level: tasks by class, blocks, 16-source stages of matrix-core blocks, vector entries
+        for (i64 l = 0; l < D.nlevels; ++l) {
+            i64 nb = 0, stages = 0, vec = 0, vblk = 0, maxst = 0, rows = 0;
+            for (i64 t = P.level_ptr[l]; t < P.level_ptr[l + 1]; ++t)
+                for (i64 b = P.task_ptr[t]; b < P.task_ptr[t + 1]; ++b) {
+                    const BlockHeader &h = P.hdr[b];
+                    ++nb;
+                    if (h.rc == 16) { stages += h.nsrc / 16; maxst = std::max<i64>(maxst, h.nsrc / 16); }
+                    else { vec += (i64)h.nsrc * h.rc; ++vblk; }
+                    for (int r = 0; r < h.rc; ++r) rows += P.src_idx[h.src_off + r] != BlockProgram::kNone;
+                }
+            fprintf(stderr, "L%lld tasks %d/%d/%d blocks %lld rows %lld mfma_stages %lld max %lld vec_blocks %lld vec_entries %lld clusters %d\n",
+                    (long long)l, D.levels[l].ntasks[0], D.levels[l].ntasks[1], D.levels[l].ntasks[2], (long long)nb, (long long)rows,
+                    (long long)stages, (long long)maxst, (long long)vblk, (long long)vec, D.levels[l].nclusters);
+        }
+    }
     D.task_ptr.upload(P.task_ptr);
     D.hdr.upload(P.hdr);
     // the kernels fetch ids and coefficients a wavefront at a time (clamped lane offsets), never past these ends
@@ -199,7 +216,11 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
 {
     if (nrhs <= 0 || n_ == 0) return;
     if (nrhs == 1 && (layout == 0 || ld == 1)) {
-        run_single(dX, stream);
+        // one right-hand side: a column vector is its own row-major n x 1 block.  The blocked programme needs ~170
+        // launches per sweep where the plain level programme needs one per dependency level (thousands).
+        static const bool single_levels = getenv("RSP_TRI_SINGLE") && getenv("RSP_TRI_SINGLE")[0] == '1';
+        if (single_levels) run_single(dX, stream);
+        else run_blocked(dX, 1, 1, stream);
         return;
     }
     static const bool blocked = !(getenv("RSP_TRI_BLOCKED") && getenv("RSP_TRI_BLOCKED")[0] == '0');
