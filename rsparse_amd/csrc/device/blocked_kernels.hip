@@ -388,6 +388,28 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
     }
 }
 
+// Levels with thousands of small-block tasks (the rows just above the clusters) are bound by how many row loads the
+// chip keeps in flight: this lean kernel (no matrix-core path, a third of the registers) runs them at 3-4x the occupancy.
+__global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx, double *S,
+                                                         int64_t lds, int nrhs, int nchunks)
+{
+    const int lane = threadIdx.x & 63;
+    const int pair = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int t = pair / nchunks;
+    if (t >= ntasks) return;
+    const int col = (pair - t * nchunks) * 64 + lane;
+    const bool live = col < nrhs;
+    const int64_t bend = B.task_ptr[task_begin + t + 1];
+    for (int64_t b = B.task_ptr[task_begin + t]; b < bend; ++b) {
+        const BlockHeader h = B.hdr[b];
+        switch (h.rc) {
+            case 1: run_block_vec<1>(h, B, X, ldx, S, lds, col, live, lane); break;
+            case 2: run_block_vec<2>(h, B, X, ldx, S, lds, col, live, lane); break;
+            default: run_block_vec<4>(h, B, X, ldx, S, lds, col, live, lane); break;
+        }
+    }
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(512) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
                                                     int nchunks)

@@ -96,9 +96,9 @@ struct BlockedProgram {
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
     struct Level {
-        i64 task_begin[3];  // by split class: 1, 4, 8 wavefronts per (block, 64 columns)
-        int ntasks[3];
-        i64 block_begin[3];  // first block of each class (split classes: one block per task)
+        i64 task_begin[4];  // by class (BlockProgram::level_class_ptr)
+        int ntasks[4];
+        i64 block_begin[4];  // first block of each class (split classes: one block per task)
         i64 cluster_begin;
         int nclusters;
     };
@@ -149,5 +149,6 @@ class TriSolver {
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)
 constexpr i64 kTaskEntriesMulti = 2048;   // unblocked fallback programme
 constexpr i64 kTaskEntriesSingle = 512;
+constexpr i64 kSmallLaunchWaves = 2048;  // small-block tasks of a level get their own launch from this many wavefronts
 
 }  // namespace rsp

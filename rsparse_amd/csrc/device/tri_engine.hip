@@ -115,12 +115,13 @@ void TriSolver::build_blocked()
     D.launches = 0;
     for (i64 l = 0; l < D.nlevels; ++l) {
         BlockedProgram::Level lv;
-        for (int c = 0; c < 3; ++c) {
-            lv.task_begin[c] = P.level_class_ptr[3 * l + c];
-            lv.ntasks[c] = (int)(P.level_class_ptr[3 * l + c + 1] - P.level_class_ptr[3 * l + c]);
+        constexpr int NC = BlockProgram::kClasses;
+        for (int c = 0; c < NC; ++c) {
+            lv.task_begin[c] = P.level_class_ptr[NC * l + c];
+            lv.ntasks[c] = (int)(P.level_class_ptr[NC * l + c + 1] - P.level_class_ptr[NC * l + c]);
             lv.block_begin[c] = P.task_ptr[lv.task_begin[c]];
         }
-        D.launches += (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2]) > 0;
+        D.launches += (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2] + lv.ntasks[3]) > 0;
         lv.cluster_begin = P.cluster_level_ptr[l];
         lv.nclusters = (int)(P.cluster_level_ptr[l + 1] - P.cluster_level_ptr[l]);
         D.launches += lv.nclusters > 0;
@@ -137,8 +138,8 @@ void TriSolver::build_blocked()
                     else { vec += (i64)h.nsrc * h.rc; ++vblk; }
                     for (int r = 0; r < h.rc; ++r) rows += P.src_idx[h.src_off + r] != BlockProgram::kNone;
                 }
-            fprintf(stderr, "L%lld tasks %d/%d/%d blocks %lld rows %lld mfma_stages %lld max %lld vec_blocks %lld vec_entries %lld clusters %d\n",
-                    (long long)l, D.levels[l].ntasks[0], D.levels[l].ntasks[1], D.levels[l].ntasks[2], (long long)nb, (long long)rows,
+            fprintf(stderr, "L%lld tasks %d/%d/%d/%d blocks %lld rows %lld mfma_stages %lld max %lld vec_blocks %lld vec_entries %lld clusters %d\n",
+                    (long long)l, D.levels[l].ntasks[0], D.levels[l].ntasks[1], D.levels[l].ntasks[2], D.levels[l].ntasks[3], (long long)nb, (long long)rows,
                     (long long)stages, (long long)maxst, (long long)vblk, (long long)vec, D.levels[l].nclusters);
         }
     }
@@ -169,22 +170,29 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     const int nchunks = (int)((nrhs + 63) / 64);
     // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
     const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)scratch_.get() % 16) == 0;
+    static const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);  // tests force the lean launch with 1
     for (const auto &lv : P.levels) {
         if (lv.nclusters)  // clusters and block tasks of one level are independent of each other
             hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * nchunks)), dim3(64),
                                (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs,
                                P.cluster_slots, (int)env_or("RSP_CLUSTER_MODE", 0));
-        if (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2]) {
+        // many small-block tasks: their own lean, high-occupancy launch; a few ride along with class 1
+        const bool small_alone = lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves;
+        if (small_alone)
+            hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)(((i64)lv.ntasks[0] * nchunks + 3) / 4)), dim3(256), 0, stream, A,
+                               lv.task_begin[0], lv.ntasks[0], X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+        const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
+        if (n01 + lv.ntasks[2] + lv.ntasks[3]) {
             dev::LevelDesc L;
-            L.task_begin = lv.task_begin[0];
-            L.block_begin[0] = lv.block_begin[1];
-            L.block_begin[1] = lv.block_begin[2];
-            L.ntasks = lv.ntasks[0];
-            L.nblk[0] = lv.ntasks[1];
-            L.nblk[1] = lv.ntasks[2];
-            L.wg0 = (int)(((i64)lv.ntasks[0] * nchunks + 7) / 8);
-            L.wg1 = (int)(((i64)lv.ntasks[1] * nchunks + 1) / 2);
-            L.wg2 = (int)((i64)lv.ntasks[2] * nchunks);
+            L.task_begin = small_alone ? lv.task_begin[1] : lv.task_begin[0];
+            L.block_begin[0] = lv.block_begin[2];
+            L.block_begin[1] = lv.block_begin[3];
+            L.ntasks = n01;
+            L.nblk[0] = lv.ntasks[2];
+            L.nblk[1] = lv.ntasks[3];
+            L.wg0 = (int)(((i64)n01 * nchunks + 7) / 8);
+            L.wg1 = (int)(((i64)lv.ntasks[2] * nchunks + 1) / 2);
+            L.wg2 = (int)((i64)lv.ntasks[3] * nchunks);
             const unsigned wgs = (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
             if (fast)
                 hipLaunchKernelGGL(dev::solve_level<true>, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs,

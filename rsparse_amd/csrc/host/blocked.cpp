@@ -565,19 +565,24 @@ class Builder {
             for (i64 c = 0; c < nclusters; ++c)
                 if (!read[emit_order_[c]]) cluster_level_[c] = (int32_t)(nlev - 1);
         }
-        // inside a level, tasks are grouped by split class (how many wavefronts share one block)
-        auto split_class = [&](i64 t) {
+        // inside a level, tasks are grouped by class: 0 = only small (vector-path) blocks, 1 = one wavefront per
+        // (task, 64 columns) with at least one matrix-core block, 2 / 3 = one matrix-core block whose sources are
+        // split over 4 / 8 wavefronts
+        constexpr int NC = BlockProgram::kClasses;
+        auto task_class = [&](i64 t) {
             const BlockHeader &h = P_.hdr[task_first_blk_[t]];
-            if (task_nblk_[t] != 1 || h.rc != 16 || h.nsrc < kSplitSources) return 0;
-            return h.nsrc > 4 * kSplitSources ? 2 : 1;
+            if (task_nblk_[t] == 1 && h.rc == 16 && h.nsrc >= kSplitSources) return h.nsrc > 4 * kSplitSources ? 3 : 2;
+            for (i64 b = task_first_blk_[t]; b < task_first_blk_[t] + task_nblk_[t]; ++b)
+                if (P_.hdr[b].rc == 16) return 1;
+            return 0;
         };
-        P_.level_class_ptr.assign(3 * nlev + 1, 0);
-        for (i64 t = 0; t < ntasks; ++t) P_.level_class_ptr[3 * task_level_[t] + split_class(t) + 1]++;
-        for (i64 k = 0; k < 3 * nlev; ++k) P_.level_class_ptr[k + 1] += P_.level_class_ptr[k];
+        P_.level_class_ptr.assign(NC * nlev + 1, 0);
+        for (i64 t = 0; t < ntasks; ++t) P_.level_class_ptr[NC * task_level_[t] + task_class(t) + 1]++;
+        for (i64 k = 0; k < NC * nlev; ++k) P_.level_class_ptr[k + 1] += P_.level_class_ptr[k];
         P_.level_ptr.assign(nlev + 1, 0);
-        for (i64 l = 0; l <= nlev; ++l) P_.level_ptr[l] = P_.level_class_ptr[3 * l];
+        for (i64 l = 0; l <= nlev; ++l) P_.level_ptr[l] = P_.level_class_ptr[NC * l];
         std::vector<i64> fill(P_.level_class_ptr.begin(), P_.level_class_ptr.end() - 1), order(ntasks);
-        for (i64 t = 0; t < ntasks; ++t) order[fill[3 * task_level_[t] + split_class(t)]++] = t;
+        for (i64 t = 0; t < ntasks; ++t) order[fill[NC * task_level_[t] + task_class(t)]++] = t;
         std::vector<BlockHeader> hdr(P_.hdr.size());
         P_.task_ptr.assign(ntasks + 1, 0);
         i64 at = 0;

@@ -156,6 +156,7 @@ struct GroupRec {       // 64 bytes: four 16-byte loads, the same address in eve
 };
 struct BlockProgram {
     static constexpr int32_t kNone = INT32_MIN;
+    static constexpr int kClasses = 4;
     std::vector<BlockHeader> hdr;    // per block
     // pools
     std::vector<int32_t> src_idx;    // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
@@ -168,8 +169,9 @@ struct BlockProgram {
     // schedule
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
     std::vector<i64> level_ptr;      // block tasks of level l
-    std::vector<i64> level_class_ptr;  // 3 entries per level: tasks of split class 0 (one wavefront per block and 64
-                                       // columns), 1 (4 wavefronts share the block's sources), 2 (8 wavefronts)
+    std::vector<i64> level_class_ptr;  // kClasses entries per level: tasks of class 0 (vector-path blocks only), 1 (one
+                                       // wavefront per task and 64 columns, matrix-core blocks), 2 (4 wavefronts share
+                                       // the block's sources), 3 (8 wavefronts)
     std::vector<i64> cluster_level_ptr;  // clusters of level l (same level numbering)
     i64 scratch_rows = 0;
     i64 big_chains = 0, inverted_rows = 0, padded_entries = 0, cluster_rows = 0, cluster_entries = 0;
