@@ -27,6 +27,24 @@ def bytes_trisolve(n, nnz, k):
     return nnz * 12 + (n + 1) * 4 + 16 * n * k
 
 
+def measured_traffic(cfg):
+    """HBM bytes of one step from the committed rocprofv3 --pmc passes (profiles/*_summary.json, made by
+    tools/pmc.sh + tools/collect_profiles.py on this same command), or None when no pass matches this configuration
+    (same matrix, right-hand sides and programme): counters cannot be read from inside the timed process."""
+    import glob
+    keys = ("n", "nnz_L", "nrhs_per_gpu", "lsolve_tasks", "lsolve_launches", "ltsolve_launches")
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        t, c = d.get("traffic"), d.get("config", {})
+        if t and all(c.get(k) == cfg.get(k) for k in keys):
+            best = t["hbm_bytes_per_step"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,7 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nrhs", type=int, default=256)
     ap.add_argument("--grid", type=int, default=1024, help="Laplacian grid side (1024 = the headline configuration)")
-    ap.add_argument("--cpu-rhs", type=int, default=48, help="right-hand sides of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rhs", type=int, default=160, help="right-hand sides of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--skip-extras", action="store_true", help="skip the single-RHS cholsol timing")
     args = ap.parse_args()
 
@@ -210,12 +228,14 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "solve_level_blocked (all level launches of one lsolve+ltsolve step)",
+                "kernel": "solve_level + solve_level_small + solve_clusters: all launches of one lsolve+ltsolve step "
+                          "(one 'launch' of the path = one step; HIP events on the launch stream)",
             },
             "setup": setup,
             "check": check,
             "extras": extras,
         }
+        out["roofline"]["traffic"] = measured_traffic(out["config"])
         # ---- CPU baseline: the oracle (C restatement of the reference's loops), 1 thread, same factor -------
         if args.cpu_rhs > 0 and world == 1:
             from oracle import pyoracle as orc

@@ -181,7 +181,7 @@ constexpr i64 kSplitSources = 64;    // matrix-core blocks with at least this ma
                                      // with more than 4x this over 8
 constexpr i64 kMaxBlockSources = 1024;  // longer source lists become partial sums (scratch rows) plus a combine block
 constexpr int kClusterSlots = 48;    // default LDS slots per cluster (24 KB per wavefront at 64 right-hand sides)
-constexpr i64 kTaskBlocks = 2;       // default number of dependent blocks one wavefront runs back to back
+constexpr i64 kTaskBlocks = 1;       // default number of dependent blocks one wavefront runs back to back (measured: 1 beats 2, 3)
 BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots);
 
 // Host-side validator of a programme (debug aid, never a solve path: it takes no user data).  Replays the programme

@@ -1,9 +1,10 @@
 """Condense rocprofv3 outputs under gpurun_out/ into the small, tracked summaries under profiles/.
-usage: collect_profiles.py <tag> <stats_dir> <launches_per_step> [<fetch_dir> <write_dir>]"""
+usage: collect_profiles.py <tag> <stats_dir> <launches_per_step> <bench.json of that run> [<fetch_dir> <write_dir>]"""
 import csv, glob, json, sys, collections
 
 tag, stats_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
-out = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rhs 0 --skip-extras"}
+bench = json.load(open(sys.argv[4]))
+out = {"tag": tag, "config": bench["config"], "ms_per_step_under_profiler": bench["ms_per_step"], "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rhs 0 --skip-extras"}
 # 1. kernel stats (whole process) -> csv copy restricted to our kernels
 f = glob.glob(stats_dir + '/**/*_kernel_stats.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'rsp::dev' in r['Name']]
@@ -25,13 +26,13 @@ out["step"] = {"launches": n, "kernel_us": {k: {"launches": v[0], "total_us": ro
                "sum_us": round(sum(v[1] for v in by.values()), 1),
                "span_us": round((int(last[-1]['End_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e3, 1)}
 # 3. HBM traffic of one step from separate --pmc passes (KB units; gfx950: FETCH_SIZE reads 1/2 of wide coalesced streams)
-if len(sys.argv) > 5:
+if len(sys.argv) > 6:
     def total(d, name):
         f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
         rs = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == name and ('solve_level' in r['Kernel_Name'] or 'solve_clusters' in r['Kernel_Name'])]
         rs.sort(key=lambda r: int(r['Dispatch_Id']))
         return sum(float(r['Counter_Value']) for r in rs[-n:])
-    fetch_kb, write_kb = total(sys.argv[4], 'FETCH_SIZE'), total(sys.argv[5], 'WRITE_SIZE')
+    fetch_kb, write_kb = total(sys.argv[5], 'FETCH_SIZE'), total(sys.argv[6], 'WRITE_SIZE')
     out["traffic"] = {"FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                       "hbm_bytes_per_step": int((2 * fetch_kb + write_kb) * 1024),
                       "note": "separate --pmc passes; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are counted"}
