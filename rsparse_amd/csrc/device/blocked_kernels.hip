@@ -177,16 +177,22 @@ struct PanelIds {
     double tinv[4];            // A operands of the inverse triangle
 };
 
-__device__ __forceinline__ void load_panel_ids(PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c, bool lead)
+__device__ __forceinline__ void load_panel_tinv(PanelIds &P, const BlockHeader h, const PanelCtx &c)
+{
+    const double *tinv = c.cf + (int64_t)h.nsrc * 16;  // padded pool: in bounds without a triangle
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P.tinv[k] = tinv[k * 64 + c.lane];
+}
+
+__device__ __forceinline__ void load_panel_ids(PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c, bool lead,
+                                               bool with_tinv)
 {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         P.dest[s] = ids[4 * s + c.g];
         P.init[s] = lead ? ids[16 + 4 * s + c.g] : RSP_NONE;
     }
-    const double *tinv = c.cf + (int64_t)h.nsrc * 16;  // padded pool: in bounds without a triangle
-#pragma unroll
-    for (int k = 0; k < 4; ++k) P.tinv[k] = tinv[k * 64 + c.lane];
+    if (with_tinv) load_panel_tinv(P, h, c);
 }
 
 // rows of the block -> acc (register s <- unknown 4s + g); kNone = zero
@@ -216,31 +222,48 @@ __device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t (
 }
 
 // acc = init rows - coef[st_begin*16 .. st_end*16) * sources.  `lead`: this wavefront loads the initial values.
-template <bool FAST>
+// PIPE: two stages of registers, the next stage's loads in flight during this stage's MFMAs -- the shortest critical
+// path, for levels with little work.  !PIPE: one stage of registers (half the footprint, twice the wavefronts per CU):
+// a stage's loads are only issued after the previous stage's MFMAs, and it is the OTHER wavefronts of the CU that
+// cover the wait -- the better trade on levels with thousands of blocks, where throughput is what counts.
+template <bool FAST, bool PIPE>
 __device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
     const int last = st_end - 1;
     const bool any = st_begin < st_end;  // wave-uniform; a block may have no sources at all
-    int32_t idA[4], idB[4];
-    Stage A, B;
+    int32_t idA[4];
+    Stage A;
     // round trip 2
-    load_panel_ids(P, ids, h, c, lead);
-    if (any) {
-        load_ids(idA, c, st_begin);
-        load_ids(idB, c, min(st_begin + 1, last));
-    }
-    // round trip 3
-    panel_load_rows<FAST>(acc, P.init, c);
-    if (!any) return;
-    load_stage<FAST>(A, idA, c, st_begin);
-    for (int s = st_begin; s < st_end; s += 2) {
-        load_stage<FAST>(B, idB, c, min(s + 1, last));
-        load_ids(idA, c, min(s + 2, last));
-        mfma_stage(acc, A);
-        load_stage<FAST>(A, idA, c, min(s + 2, last));
-        load_ids(idB, c, min(s + 3, last));
-        if (s + 1 < st_end) mfma_stage(acc, B);
+    load_panel_ids(P, ids, h, c, lead, PIPE);
+    if (any) load_ids(idA, c, st_begin);
+    if (PIPE) {
+        int32_t idB[4];
+        Stage B;
+        if (any) load_ids(idB, c, min(st_begin + 1, last));
+        // round trip 3
+        panel_load_rows<FAST>(acc, P.init, c);
+        if (!any) return;
+        load_stage<FAST>(A, idA, c, st_begin);
+        for (int s = st_begin; s < st_end; s += 2) {
+            load_stage<FAST>(B, idB, c, min(s + 1, last));
+            load_ids(idA, c, min(s + 2, last));
+            mfma_stage(acc, A);
+            load_stage<FAST>(A, idA, c, min(s + 2, last));
+            load_ids(idB, c, min(s + 3, last));
+            if (s + 1 < st_end) mfma_stage(acc, B);
+        }
+    } else {
+        panel_load_rows<FAST>(acc, P.init, c);
+        if (any) {
+            load_stage<FAST>(A, idA, c, st_begin);
+            for (int s = st_begin; s < st_end; ++s) {
+                load_ids(idA, c, min(s + 1, last));
+                mfma_stage(acc, A);
+                load_stage<FAST>(A, idA, c, min(s + 1, last));
+            }
+        }
+        load_panel_tinv(P, h, c);
     }
 }
 
@@ -294,14 +317,14 @@ __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArr
     return c;
 }
 
-template <bool FAST>
+template <bool FAST, bool PIPE>
 __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockArrays &B, double *X, int64_t ldx, double *S, int64_t lds,
                                                int cw, int nrhs, int lane)
 {
     const PanelCtx c = make_ctx(h, B, X, ldx, S, lds, cw, nrhs, lane);
     PanelIds P;
     f64x4 acc[4];
-    panel_gather<FAST>(acc, P, B.src_idx + h.src_off, h, c, 0, h.nsrc >> 4, true);
+    panel_gather<FAST, PIPE>(acc, P, B.src_idx + h.src_off, h, c, 0, h.nsrc >> 4, true);
     panel_finish<FAST>(acc, P, h, c, X, S);
 }
 
@@ -323,7 +346,7 @@ struct LevelDesc {
 };
 
 // class 0: the blocks of a task run in order
-template <bool FAST>
+template <bool FAST, bool PIPE>
 __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task, int chunk, double *X, int64_t ldx, double *S, int64_t lds,
                                          int nrhs, int lane)
 {
@@ -334,7 +357,7 @@ __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task, int
     for (int64_t b = B.task_ptr[task]; b < bend; ++b) {
         const BlockHeader h = B.hdr[b];
         switch (h.rc) {
-            case 16: run_block_mfma<FAST>(h, B, X, ldx, S, lds, cw, nrhs, lane); break;
+            case 16: run_block_mfma<FAST, PIPE>(h, B, X, ldx, S, lds, cw, nrhs, lane); break;
             case 1: run_block_vec<1>(h, B, X, ldx, S, lds, col, live, lane); break;
             case 2: run_block_vec<2>(h, B, X, ldx, S, lds, col, live, lane); break;
             default: run_block_vec<4>(h, B, X, ldx, S, lds, col, live, lane); break;
@@ -354,7 +377,7 @@ __device__ __forceinline__ void split_item(int q, int n, int nchunks, int &blk, 
 
 // W wavefronts (w = 0..W-1) share one matrix-core block: contiguous ranges of its stages each, partial accumulators
 // meet in LDS (red: (W - 1) x 8 KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
-template <int W, bool FAST>
+template <int W, bool FAST, bool PIPE>
 __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t block, int chunk, int w, double *red, double *X,
                                           int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
@@ -366,7 +389,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
         h = B.hdr[block];
         c = make_ctx(h, B, X, ldx, S, lds, chunk * 64, nrhs, lane);
         const int nst = h.nsrc >> 4;
-        panel_gather<FAST>(acc, P, B.src_idx + h.src_off, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
+        panel_gather<FAST, PIPE>(acc, P, B.src_idx + h.src_off, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
         if (w > 0) {
             double *mine = red + (size_t)(w - 1) * 1024 + lane;
 #pragma unroll
@@ -410,8 +433,8 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
     }
 }
 
-template <bool FAST>
-__global__ __launch_bounds__(512) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
+template <bool FAST, bool PIPE>
+__global__ __launch_bounds__(512, PIPE ? 2 : 4) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
                                                     int nchunks)
 {
     extern __shared__ double red[];  // 7 x 8 KiB
@@ -422,17 +445,17 @@ __global__ __launch_bounds__(512) void solve_level(BlockArrays B, LevelDesc L, d
     if (item < L.wg0) {  // 8 (task, chunk) pairs
         const int pair = item * 8 + w;
         const int t = pair / nchunks;
-        if (t < L.ntasks) run_task<FAST>(B, L.task_begin + t, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
+        if (t < L.ntasks) run_task<FAST, PIPE>(B, L.task_begin + t, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
     } else if (item < L.wg0 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
         const int q = (item - L.wg0) * 2 + (w >> 2);
         const bool valid = q < L.nblk[0] * nchunks;
         int blk = 0, chunk = 0;
         if (valid) split_item(q, L.nblk[0], nchunks, blk, chunk);
-        run_split<4, FAST>(B, valid, L.block_begin[0] + blk, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
+        run_split<4, FAST, PIPE>(B, valid, L.block_begin[0] + blk, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
     } else if (item < L.wg0 + L.wg1 + L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
         int blk, chunk;
         split_item(item - L.wg0 - L.wg1, L.nblk[1], nchunks, blk, chunk);
-        run_split<8, FAST>(B, true, L.block_begin[1] + blk, chunk, w, red, X, ldx, S, lds, nrhs, lane);
+        run_split<8, FAST, PIPE>(B, true, L.block_begin[1] + blk, chunk, w, red, X, ldx, S, lds, nrhs, lane);
     }
 }
 

@@ -170,6 +170,7 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     const int nchunks = (int)((nrhs + 63) / 64);
     // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
     const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)scratch_.get() % 16) == 0;
+    static const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
     static const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);  // tests force the lean launch with 1
     for (const auto &lv : P.levels) {
         if (lv.nclusters)  // clusters and block tasks of one level are independent of each other
@@ -194,12 +195,11 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
             L.wg1 = (int)(((i64)lv.ntasks[2] * nchunks + 1) / 2);
             L.wg2 = (int)((i64)lv.ntasks[3] * nchunks);
             const unsigned wgs = (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
-            if (fast)
-                hipLaunchKernelGGL(dev::solve_level<true>, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs,
-                                   (int)nrhs, nchunks);
-            else
-                hipLaunchKernelGGL(dev::solve_level<false>, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs,
-                                   (int)nrhs, nchunks);
+            // few workgroups: latency counts, pipelined variant; many: the lean variant at twice the occupancy
+            const bool pipe = wgs < (unsigned)lean_wgs;
+            auto kernel = fast ? (pipe ? dev::solve_level<true, true> : dev::solve_level<true, false>)
+                               : (pipe ? dev::solve_level<false, true> : dev::solve_level<false, false>);
+            hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
         }
     }
     RSP_HIP(hipGetLastError());
