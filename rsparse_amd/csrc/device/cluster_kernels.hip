@@ -70,15 +70,22 @@ __device__ __forceinline__ void run_group(const GroupRegs &r, double *xs_lane, d
     }
 }
 
-// one 64-thread workgroup (= one wavefront) per (cluster, 64 columns); dynamic LDS = slots * 512 + 1024 bytes
-__global__ __launch_bounds__(64) void solve_clusters(ClusterArrays C, int64_t cluster_begin, int nchunks, double *__restrict__ X,
-                                                     int64_t ldx, int nrhs, int slots, int mode)
+// One wavefront per (cluster, 64 columns), wavefronts completely independent of each other (no barrier).  A workgroup
+// holds the `cpw` column chunks of ONE cluster side by side, so the chip reads and writes whole contiguous rows of X
+// at about the same time (DRAM page locality) instead of a 512-byte piece every 2 KiB.
+// Dynamic LDS = cpw * (slots * 512 + 1024) bytes.
+__global__ __launch_bounds__(256) void solve_clusters(ClusterArrays C, int64_t cluster_begin, int nchunks, double *__restrict__ X,
+                                                      int64_t ldx, int nrhs, int slots, int cpw)
 {
-    extern __shared__ double xs[];
+    extern __shared__ double lds_all[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double *xs = lds_all + (size_t)wv * (slots * 64 + 128);
     v4i *ring = reinterpret_cast<v4i *>(xs + (size_t)slots * 64);  // 16 group records
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x / nchunks;
-    const int chunk = blockIdx.x - c * nchunks;
+    const int lane = threadIdx.x & 63;
+    const int per = (nchunks + cpw - 1) / cpw;  // workgroups per cluster
+    const int c = blockIdx.x / per;
+    const int chunk = (blockIdx.x - c * per) * cpw + wv;
+    if (chunk >= nchunks) return;
     const int col = chunk * 64 + lane;
     const bool live = col < nrhs;
     const ClusterHeader h = C.hdr[cluster_begin + c];
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(64) void solve_clusters(ClusterArrays C, int64_t cl
 
     double *xs_lane = xs + lane;
     double acc = 0.0;
-    for (int b0 = 0; b0 < (mode == 1 ? 0 : ng); b0 += 16) {
+    for (int b0 = 0; b0 < ng; b0 += 16) {
         ring[lane] = blk;
         blk = gsrc[min(4 * (b0 + 16) + lane, nq - 1)];  // next block: in flight while this one is executed
         const int nb = min(16, ng - b0);

@@ -1,5 +1,6 @@
 // TriSolver: uploads a triangular factor in execution order and runs the level-scheduled kernels.
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 
 #include "engine.hpp"
@@ -151,9 +152,8 @@ void TriSolver::build_blocked()
     D.clusters.upload(P.clusters);
     D.cluster_ids.upload(P.cluster_ids);
     D.groups.upload(P.groups);
-    if ((size_t)D.cluster_slots * 512 + 1024 > 64 * 1024)
-        RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    D.cluster_slots * 512 + 1024));
+    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                4 * (D.cluster_slots * 512 + 1024)));
 }
 
 void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
@@ -170,13 +170,16 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     const int nchunks = (int)((nrhs + 63) / 64);
     // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
     const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)scratch_.get() % 16) == 0;
+    static const i64 cluster_cpw = env_or("RSP_CLUSTER_CPW", 2);
     static const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
     static const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);  // tests force the lean launch with 1
     for (const auto &lv : P.levels) {
-        if (lv.nclusters)  // clusters and block tasks of one level are independent of each other
-            hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * nchunks)), dim3(64),
-                               (size_t)P.cluster_slots * 512 + 1024, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs,
-                               P.cluster_slots, (int)env_or("RSP_CLUSTER_MODE", 0));
+        if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
+            const int cpw = (int)std::min<i64>(std::min<i64>(nchunks, 4), cluster_cpw);
+            const size_t per_wave = (size_t)P.cluster_slots * 512 + 1024;
+            hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * ((nchunks + cpw - 1) / cpw))), dim3(64 * cpw),
+                               per_wave * cpw, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs, P.cluster_slots, cpw);
+        }
         // many small-block tasks: their own lean, high-occupancy launch; a few ride along with class 1
         const bool small_alone = lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves;
         if (small_alone)

@@ -180,7 +180,8 @@ constexpr i64 kBigChain = 32;        // chains longer than this are replaced by 
 constexpr i64 kSplitSources = 64;    // matrix-core blocks with at least this many sources are split over 4 wavefronts,
                                      // with more than 4x this over 8
 constexpr i64 kMaxBlockSources = 1024;  // longer source lists become partial sums (scratch rows) plus a combine block
-constexpr int kClusterSlots = 48;    // default LDS slots per cluster (24 KB per wavefront at 64 right-hand sides)
+constexpr int kClusterSlots = 24;    // default LDS slots per cluster (12 KB per wavefront at 64 right-hand sides; measured
+                                     // at C2: 24 slots beat 16, 32, 40 and 48 -- occupancy outweighs coverage)
 constexpr i64 kTaskBlocks = 1;       // default number of dependent blocks one wavefront runs back to back (measured: 1 beats 2, 3)
 BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots);
 
