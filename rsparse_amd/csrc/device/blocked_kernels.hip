@@ -417,7 +417,9 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
                                                          int64_t lds, int nrhs, int nchunks)
 {
     const int lane = threadIdx.x & 63;
-    const int pair = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int per_xcd = (int)(gridDim.x >> 3);  // XCD-aware placement as in solve_level: consecutive tasks share an XCD
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int pair = __builtin_amdgcn_readfirstlane((int)(item * 4 + (threadIdx.x >> 6)));
     const int t = pair / nchunks;
     if (t >= ntasks) return;
     const int col = (pair - t * nchunks) * 64 + lane;
@@ -442,20 +444,21 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void solve_level(BlockArrays B, 
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..7
     const int per_xcd = (int)(gridDim.x >> 3);                              // the grid is a multiple of 8 workgroups
     const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (item < L.wg0) {  // 8 (task, chunk) pairs
-        const int pair = item * 8 + w;
-        const int t = pair / nchunks;
-        if (t < L.ntasks) run_task<FAST, PIPE>(B, L.task_begin + t, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
-    } else if (item < L.wg0 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
-        const int q = (item - L.wg0) * 2 + (w >> 2);
+    // longest work first: the 8-wavefront blocks, then the 4-wavefront ones, then the small tasks fill the tail
+    if (item < L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
+        int blk, chunk;
+        split_item(item, L.nblk[1], nchunks, blk, chunk);
+        run_split<8, FAST, PIPE>(B, true, L.block_begin[1] + blk, chunk, w, red, X, ldx, S, lds, nrhs, lane);
+    } else if (item < L.wg2 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
+        const int q = (item - L.wg2) * 2 + (w >> 2);
         const bool valid = q < L.nblk[0] * nchunks;
         int blk = 0, chunk = 0;
         if (valid) split_item(q, L.nblk[0], nchunks, blk, chunk);
         run_split<4, FAST, PIPE>(B, valid, L.block_begin[0] + blk, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
-    } else if (item < L.wg0 + L.wg1 + L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
-        int blk, chunk;
-        split_item(item - L.wg0 - L.wg1, L.nblk[1], nchunks, blk, chunk);
-        run_split<8, FAST, PIPE>(B, true, L.block_begin[1] + blk, chunk, w, red, X, ldx, S, lds, nrhs, lane);
+    } else if (item < L.wg2 + L.wg1 + L.wg0) {  // 8 (task, chunk) pairs
+        const int pair = (item - L.wg2 - L.wg1) * 8 + w;
+        const int t = pair / nchunks;
+        if (t < L.ntasks) run_task<FAST, PIPE>(B, L.task_begin + t, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
     }
 }
 

@@ -74,17 +74,26 @@ __device__ __forceinline__ void run_group(const GroupRegs &r, double *xs_lane, d
 // holds the `cpw` column chunks of ONE cluster side by side, so the chip reads and writes whole contiguous rows of X
 // at about the same time (DRAM page locality) instead of a 512-byte piece every 2 KiB.
 // Dynamic LDS = cpw * (slots * 512 + 1024) bytes.
-__global__ __launch_bounds__(256) void solve_clusters(ClusterArrays C, int64_t cluster_begin, int nchunks, double *__restrict__ X,
-                                                      int64_t ldx, int nrhs, int slots, int cpw)
+__global__ __launch_bounds__(256) void solve_clusters(ClusterArrays C, int64_t cluster_begin, int nclusters, int nchunks,
+                                                      double *__restrict__ X, int64_t ldx, int nrhs, int slots, int cpw)
 {
     extern __shared__ double lds_all[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double *xs = lds_all + (size_t)wv * (slots * 64 + 128);
     v4i *ring = reinterpret_cast<v4i *>(xs + (size_t)slots * 64);  // 16 group records
     const int lane = threadIdx.x & 63;
+    // XCD-aware placement (blockIdx % 8 share an XCD and its L2): every XCD walks a contiguous range of work items, and
+    // items are ordered (group of 16 clusters, chunk group, cluster), so the workgroups an XCD runs together are
+    // neighbouring clusters on the same columns -- in a transposed solve they read the same ancestor rows.
     const int per = (nchunks + cpw - 1) / cpw;  // workgroups per cluster
-    const int c = blockIdx.x / per;
-    const int chunk = (blockIdx.x - c * per) * cpw + wv;
+    const int per_xcd = (int)(gridDim.x >> 3);  // the grid is a multiple of 8 workgroups
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= nclusters * per) return;
+    const int grp = item / (16 * per), r = item - grp * (16 * per);
+    const int in_grp = min(16, nclusters - grp * 16);
+    const int cg = r / in_grp;
+    const int c = grp * 16 + (r - cg * in_grp);
+    const int chunk = cg * cpw + wv;
     if (chunk >= nchunks) return;
     const int col = chunk * 64 + lane;
     const bool live = col < nrhs;

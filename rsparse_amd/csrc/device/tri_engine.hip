@@ -177,14 +177,15 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
         if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
             const int cpw = (int)std::min<i64>(std::min<i64>(nchunks, 4), cluster_cpw);
             const size_t per_wave = (size_t)P.cluster_slots * 512 + 1024;
-            hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)((i64)lv.nclusters * ((nchunks + cpw - 1) / cpw))), dim3(64 * cpw),
-                               per_wave * cpw, stream, C, lv.cluster_begin, nchunks, X, ld, (int)nrhs, P.cluster_slots, cpw);
+            const i64 wgs = ((i64)lv.nclusters * ((nchunks + cpw - 1) / cpw) + 7) / 8 * 8;  // whole rounds over the 8 XCDs
+            hipLaunchKernelGGL(dev::solve_clusters, dim3((unsigned)wgs), dim3(64 * cpw), per_wave * cpw, stream, C, lv.cluster_begin,
+                               lv.nclusters, nchunks, X, ld, (int)nrhs, P.cluster_slots, cpw);
         }
         // many small-block tasks: their own lean, high-occupancy launch; a few ride along with class 1
         const bool small_alone = lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves;
         if (small_alone)
-            hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)(((i64)lv.ntasks[0] * nchunks + 3) / 4)), dim3(256), 0, stream, A,
-                               lv.task_begin[0], lv.ntasks[0], X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+            hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)((((i64)lv.ntasks[0] * nchunks + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
+                               stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
         const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
         if (n01 + lv.ntasks[2] + lv.ntasks[3]) {
             dev::LevelDesc L;
