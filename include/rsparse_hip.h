@@ -74,6 +74,11 @@ int rsp_tri_solve_f64(rsp_tri *h, double *X, int64_t ldx, int64_t nrhs);
 /* dX = device pointer; layout/ld as rsp_layout; runs on `stream` (a hipStream_t, NULL = default)
  * and returns without synchronising */
 int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_t nrhs, void *stream);
+/* first then second on the same device block (lsolve + ltsolve of cholsol, lsolve + usolve of lusol), row-major only:
+ * wide blocks are cut into two column halves that go through both sweeps on two streams, so the nearly empty levels
+ * at the top of one half's dependency tree run beside the other half's heavy levels.  Ordered after earlier work
+ * on `stream`; later work on `stream` is ordered after both halves.  Not re-entrant per handle. */
+int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int64_t ld, int64_t nrhs, void *stream);
 /* info[0..7] = n, nnz, levels, tasks, kernel launches per sweep, device bytes of the factor copy,
  *              algorithmic bytes for one sweep of 1 rhs, longest task (rows) */
 int rsp_tri_info(const rsp_tri *h, int64_t *info);

@@ -28,6 +28,7 @@ from .api import (  # noqa: F401
     lu,
     lusol,
     schol,
+    solve_pair_dev,
     sqr,
     usolve,
     utsolve,

@@ -62,6 +62,7 @@ def lib():
             "rsp_tri_analyze": (cint, [csc, cint, C.POINTER(vp)]),
             "rsp_tri_solve_f64": (cint, [vp, vp, i64, i64]),
             "rsp_tri_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, vp]),
+            "rsp_tri_solve_pair_dev_f64": (cint, [vp, vp, vp, i64, i64, vp]),
             "rsp_tri_info": (cint, [vp, vp]),
             "rsp_tri_levels": (cint, [vp, vp]),
             "rsp_tri_free": (None, [vp]),
@@ -339,6 +340,11 @@ def validate_program(t, kind, task_blocks=0, cluster_slots=0):
     d = dict(zip(keys, rep.tolist()))
     d["max_rel_error"] = err.value
     return d
+
+
+def solve_pair_dev(first, second, ptr, ld, nrhs, stream=None):
+    """first.solve then second.solve on one row-major device block (rsp_tri_solve_pair_dev_f64)."""
+    _check(lib().rsp_tri_solve_pair_dev_f64(first._h, second._h, ptr, ld, nrhs, stream))
 
 
 class TriHandle:

@@ -152,6 +152,15 @@ int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_
     });
 }
 
+int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int64_t ld, int64_t nrhs, void *stream)
+{
+    if (!first || !second || !dX || nrhs < 0 || ld < nrhs || first->solver.n() != second->solver.n()) return RSP_BAD_INPUT;
+    return guarded([&] {
+        solve_pair_device(first->solver, second->solver, dX, ld, nrhs, (hipStream_t)stream);
+        return (int)RSP_OK;
+    });
+}
+
 int rsp_tri_info(const rsp_tri *h, int64_t *info)
 {
     if (!h || !info) return RSP_BAD_INPUT;

@@ -289,8 +289,7 @@ void CholFactor::solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool per
     const int64_t *pinv = perm ? d_pinv.get() : nullptr;
     const bool vector = (nrhs == 1 && (layout == 0 || ld == 1));
     if (layout == 1 && !perm && !vector) {  // native layout, nothing to move
-        lower_->solve_device(dB, 1, ld, nrhs, stream);
-        upper_->solve_device(dB, 1, ld, nrhs, stream);
+        solve_pair_device(*lower_, *upper_, dB, ld, nrhs, stream);  // lsolve, ltsolve (lib.rs:384-385)
         return;
     }
     work_.resize((size_t)n_ * (size_t)((layout == 1 && !vector) ? ld : nrhs));
@@ -303,8 +302,7 @@ void CholFactor::solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool per
     else
         hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, dB, W, ld, n_, (int)nrhs, pinv, 1);
     const i64 ldw = (layout == 0 || vector) ? nrhs : ld;
-    lower_->solve_device(W, 1, ldw, nrhs, stream);  // x = L \ x   (lib.rs:384)
-    upper_->solve_device(W, 1, ldw, nrhs, stream);  // x = L' \ x  (lib.rs:385)
+    solve_pair_device(*lower_, *upper_, W, ldw, nrhs, stream);  // x = L \ x, x = L' \ x  (lib.rs:384-385)
     // b = P' x : b[k] = x[pinv[k]]  (pvec, lib.rs:386)
     if (layout == 0 || vector)
         hipLaunchKernelGGL(dev::rowmajor_to_colmajor, tgrid, tblock, 0, stream, W, nrhs, dB, vector ? n_ : ld, n_, (int)nrhs, pinv, 0);

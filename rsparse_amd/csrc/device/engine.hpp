@@ -128,6 +128,9 @@ class TriSolver {
     const TriProgram &single_program() const { return single_; }
     const BlockedProgram &blocked_program() const { return blocked_; }
     i64 algorithmic_bytes(i64 nrhs) const { return nnz_ * 12 + (n_ + 1) * 4 + 16 * n_ * nrhs; }
+    // pieces of the multi-right-hand-side path that solve_pair_device drives on two streams
+    void prepare_blocked(i64 total_cols);
+    void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy);
 
    private:
     void build_program(i64 max_task_entries, TriProgram &P);
@@ -145,6 +148,9 @@ class TriSolver {
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
 };
+
+// first.solve then second.solve on one row-major device block, column halves pipelined over two streams
+void solve_pair_device(TriSolver &first, TriSolver &second, double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
 
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)
 constexpr i64 kTaskEntriesMulti = 2048;   // unblocked fallback programme

@@ -158,22 +158,49 @@ void TriSolver::build_blocked()
 
 void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
 {
+    run_window(X, ld, nrhs, 0, nrhs, stream, nullptr);
+}
+
+void TriSolver::prepare_blocked(i64 total_cols)
+{
     if (!have_blocked_) {
         build_blocked();
         have_blocked_ = true;
     }
+    if (blocked_.scratch_rows) scratch_.resize((size_t)blocked_.scratch_rows * (size_t)total_cols);
+}
+
+// Columns [col_off, col_off + nrhs) of a row-major block of `total_cols` columns whose first column is at X - col_off:
+// the scratch rows use the same column window, so two windows of one block can be in flight on two streams.
+// `after_heavy`, if given, is recorded on `stream` once 90 % of the sweep's workgroups have been launched.
+void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy)
+{
+    prepare_blocked(total_cols);
     const BlockedProgram &P = blocked_;
-    if (P.scratch_rows) scratch_.resize((size_t)P.scratch_rows * (size_t)nrhs);
+    double *const Sw = scratch_.get() ? scratch_.get() + col_off : nullptr;
+    const i64 lds = total_cols;
     const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get()};
     const dev::ClusterArrays C{P.clusters.get(), P.cluster_ids.get(), P.groups.get()};
     // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
     const int nchunks = (int)((nrhs + 63) / 64);
     // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
-    const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)scratch_.get() % 16) == 0;
+    const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && lds % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Sw % 16) == 0;
     static const i64 cluster_cpw = env_or("RSP_CLUSTER_CPW", 2);
     static const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
     static const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);  // tests force the lean launch with 1
+    // workgroups of the whole sweep (a proxy for its work), to find the point where the heavy part is over
+    i64 total = 0, done = 0;
+    if (after_heavy)
+        for (const auto &lv : P.levels)
+            total += (i64)lv.nclusters * nchunks + ((i64)(lv.ntasks[0] + lv.ntasks[1]) * nchunks + 7) / 8 + ((i64)lv.ntasks[2] * nchunks + 1) / 2 +
+                     (i64)lv.ntasks[3] * nchunks;
+    bool recorded = false;
     for (const auto &lv : P.levels) {
+        if (after_heavy && !recorded && done * 10 >= total * 9) {
+            RSP_HIP(hipEventRecord(after_heavy, stream));
+            recorded = true;
+        }
+        done += (i64)lv.nclusters * nchunks + ((i64)lv.ntasks[0] * nchunks + 7) / 8;
         if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
             const int cpw = (int)std::min<i64>(std::min<i64>(nchunks, 4), cluster_cpw);
             const size_t per_wave = (size_t)P.cluster_slots * 512 + 1024;
@@ -185,7 +212,7 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
         const bool small_alone = lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves;
         if (small_alone)
             hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)((((i64)lv.ntasks[0] * nchunks + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
-                               stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+                               stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, Sw, lds, (int)nrhs, nchunks);
         const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
         if (n01 + lv.ntasks[2] + lv.ntasks[3]) {
             dev::LevelDesc L;
@@ -203,10 +230,48 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
             const bool pipe = wgs < (unsigned)lean_wgs;
             auto kernel = fast ? (pipe ? dev::solve_level<true, true> : dev::solve_level<true, false>)
                                : (pipe ? dev::solve_level<false, true> : dev::solve_level<false, false>);
-            hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, scratch_.get(), nrhs, (int)nrhs, nchunks);
+            hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, nchunks);
+            done += wgs;
         }
     }
+    if (after_heavy && !recorded) RSP_HIP(hipEventRecord(after_heavy, stream));
     RSP_HIP(hipGetLastError());
+}
+
+// first.solve then second.solve on the same row-major block (lsolve + ltsolve of cholsol, lsolve + usolve of lusol).
+// Wide blocks are cut into two column halves that travel through both sweeps on two streams, the second half
+// starting when the heavy levels of the first half's first sweep are over: the long chains of nearly empty levels
+// at the top of the tree (latency-bound, the chip idles) then run beside the other half's heavy levels.
+void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i64 nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0 || first.n() == 0) return;
+    static const bool overlap = !(getenv("RSP_PAIR_OVERLAP") && getenv("RSP_PAIR_OVERLAP")[0] == '0');
+    const i64 nchunks = (nrhs + 63) / 64;
+    if (!overlap || nchunks < 2) {
+        first.solve_device(X, 1, ld, nrhs, stream);
+        second.solve_device(X, 1, ld, nrhs, stream);
+        return;
+    }
+    static thread_local hipStream_t aux = nullptr;
+    static thread_local hipEvent_t ev_start = nullptr, ev_heavy = nullptr, ev_done = nullptr;
+    if (!aux) {
+        RSP_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        RSP_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        RSP_HIP(hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming));
+        RSP_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    }
+    const i64 na = (nchunks + 1) / 2 * 64, nb = nrhs - na;
+    first.prepare_blocked(nrhs);   // allocations happen before anything is in flight
+    second.prepare_blocked(nrhs);
+    RSP_HIP(hipEventRecord(ev_start, stream));
+    RSP_HIP(hipStreamWaitEvent(aux, ev_start, 0));
+    first.run_window(X, ld, na, 0, nrhs, stream, ev_heavy);
+    RSP_HIP(hipStreamWaitEvent(aux, ev_heavy, 0));
+    first.run_window(X + na, ld, nb, na, nrhs, aux, nullptr);
+    second.run_window(X + na, ld, nb, na, nrhs, aux, nullptr);
+    RSP_HIP(hipEventRecord(ev_done, aux));
+    second.run_window(X, ld, na, 0, nrhs, stream, nullptr);
+    RSP_HIP(hipStreamWaitEvent(stream, ev_done, 0));
 }
 
 void TriSolver::run_single(double *x, hipStream_t stream)
