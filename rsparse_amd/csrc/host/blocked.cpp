@@ -226,12 +226,24 @@ class Builder {
             if (!cut && t > t0) {
                 const i64 r = row_at(t);
                 i64 inside = 0;
-                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) inside += mark_[G_.idx[p]] == run_id_;
+                ++stamp_id_;  // distinct members of the run among the sources (the reference allows duplicate entries)
+                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                    const i64 d = G_.idx[p];
+                    if (mark_[d] == run_id_ && stamp_[d] != stamp_id_) {
+                        stamp_[d] = stamp_id_;
+                        ++inside;
+                    }
+                }
                 cut = inside != t - t0;
             }
             if (cut) {
-                if (t - t0 > kBigChain) emit_big_chain(t0, t);
-                else emit_normal_run(t0, t);
+                if (t - t0 > kBigChain) {
+                    // the inverse of a chain costs O(w^3) on the host: very long chains are cut into pieces, each piece
+                    // seeing the earlier ones as ordinary sources (two more levels per piece)
+                    for (i64 c0 = t0; c0 < t; c0 += kMaxChain) emit_big_chain(c0, std::min(c0 + kMaxChain, t));
+                } else {
+                    emit_normal_run(t0, t);
+                }
                 t0 = t;
                 ++run_id_;
             }
@@ -260,7 +272,7 @@ class Builder {
             P_.src_idx.push_back(id_of(pos));
             const size_t base = P_.coef.size();
             P_.coef.resize(base + rc, 0.0);
-            for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] = src[k].val;
+            for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] += src[k].val;  // duplicates add up
             ++ns;
         }
         if (rc == 16 && ns > 0)  // the matrix-core path consumes sources sixteen at a time: pad with zero coefficients
@@ -371,7 +383,7 @@ class Builder {
                 const i64 s = G_.idx[p];
                 const i64 ps = pos_of(s);
                 if (ps >= a) {
-                    tri[slot * 16 + (ps - a)] = G_.val[p];
+                    tri[slot * 16 + (ps - a)] += G_.val[p];
                 } else {
                     src_.push_back(Triple{(int32_t)ps, slot, G_.val[p]});
                     if (cur_task_ >= 0 && task_of_[s] == cur_task_) chained = true;
@@ -477,7 +489,7 @@ class Builder {
             M[(size_t)(t - t0) * w + (t - t0)] = G_.diag[r];
             for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
                 const i64 ps = pos_of(G_.idx[p]);
-                if (ps >= t0) M[(size_t)(t - t0) * w + (ps - t0)] = G_.val[p];
+                if (ps >= t0) M[(size_t)(t - t0) * w + (ps - t0)] += G_.val[p];
             }
         }
         std::vector<double> Minv((size_t)w * w, 0.0);

@@ -179,3 +179,22 @@ def test_block_programme_is_valid_and_exact(task_blocks, cluster_slots):
         assert rep["max_rel_error"] <= 1e-12, (kind, rep)
         if cluster_slots == 1:
             assert rep["clusters"] == 0
+
+
+def test_block_programme_with_duplicate_entries():
+    """The reference does not sum duplicate entries (src/data.rs:345-367): its loops apply each one.  The programme must
+    add them up wherever it builds coefficients (blocks, in-block triangles, inverse diagonal blocks)."""
+    A = synth.laplacian_2d(30, 25)
+    st, L = orc.chol(A, orc.schol(A, 0))
+    n, _, p, i, x = L
+    pi, ii, xi = [0], [], []
+    for j in range(n):  # every off-diagonal entry twice, with different halves
+        rows, vals = i[p[j]:p[j + 1]], x[p[j]:p[j + 1]]
+        ii += [rows[0]] + [r for r in rows[1:] for _ in (0, 1)]
+        xi += [vals[0]] + [v * f for v in vals[1:] for f in (0.25, 0.75)]
+        pi.append(len(ii))
+    D = (n, n, np.array(pi, np.int64), np.array(ii, np.int64), np.array(xi))
+    for kind in (0, 1):
+        rep = rs.validate_program(D, kind)
+        assert rep["bad_index"] == 0 and rep["order_violations"] == 0 and rep["unwritten"] == 0, rep
+        assert rep["max_rel_error"] <= 1e-12, rep
