@@ -5,7 +5,7 @@ f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'solve_level' in r['Kernel_Name'] or 'solve_clusters' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'clusters' in r['Kernel_Name']]
-last = rows[idx[-2]:]
+last = rows[idx[-4]:]
 tot = collections.defaultdict(float); cnt = collections.Counter(); out = []
 for i, r in enumerate(last):
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
