@@ -252,14 +252,24 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i
         second.solve_device(X, 1, ld, nrhs, stream);
         return;
     }
-    static thread_local hipStream_t aux = nullptr;
-    static thread_local hipEvent_t ev_start = nullptr, ev_heavy = nullptr, ev_done = nullptr;
-    if (!aux) {
-        RSP_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        RSP_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
-        RSP_HIP(hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming));
-        RSP_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    // one auxiliary stream and three events per (thread, device), created on first use and kept
+    struct Aux {
+        hipStream_t stream = nullptr;
+        hipEvent_t start = nullptr, heavy = nullptr, done = nullptr;
+    };
+    static thread_local std::vector<Aux> per_device;
+    int device = 0;
+    RSP_HIP(hipGetDevice(&device));
+    if ((size_t)device >= per_device.size()) per_device.resize(device + 1);
+    Aux &ax = per_device[device];
+    if (!ax.stream) {
+        RSP_HIP(hipStreamCreateWithFlags(&ax.stream, hipStreamNonBlocking));
+        RSP_HIP(hipEventCreateWithFlags(&ax.start, hipEventDisableTiming));
+        RSP_HIP(hipEventCreateWithFlags(&ax.heavy, hipEventDisableTiming));
+        RSP_HIP(hipEventCreateWithFlags(&ax.done, hipEventDisableTiming));
     }
+    const hipStream_t aux = ax.stream;
+    const hipEvent_t ev_start = ax.start, ev_heavy = ax.heavy, ev_done = ax.done;
     const i64 na = (nchunks + 1) / 2 * 64, nb = nrhs - na;
     first.prepare_blocked(nrhs);   // allocations happen before anything is in flight
     second.prepare_blocked(nrhs);

@@ -8,6 +8,7 @@
 // used to pick clusters is only a heuristic, dependencies and levels are always taken from the real entries.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "sparse.hpp"
@@ -35,6 +36,14 @@ class Builder {
         task_of_.assign(n_, -1);
         stamp_.assign(n_, -1);
         cluster_of_.assign(n_, -1);
+        auto tune = [](const char *name, i64 &v) {  // experiments only; the defaults are the measured optimum at C2
+            if (const char *e = std::getenv(name)) v = std::atoll(e);
+        };
+        tune("RSP_SPLIT_SOURCES", split_sources_);
+        split8_sources_ = 4 * split_sources_;
+        tune("RSP_SPLIT8_SOURCES", split8_sources_);
+        tune("RSP_BIG_CHAIN", big_chain_);
+        tune("RSP_MAX_BLOCK_SOURCES", max_block_sources_);
     }
 
     BlockProgram run()
@@ -237,7 +246,7 @@ class Builder {
                 cut = inside != t - t0;
             }
             if (cut) {
-                if (t - t0 > kBigChain) {
+                if (t - t0 > big_chain_) {
                     // the inverse of a chain costs O(w^3) on the host: very long chains are cut into pieces, each piece
                     // seeing the earlier ones as ordinary sources (two more levels per piece)
                     for (i64 c0 = t0; c0 < t; c0 += kMaxChain) emit_big_chain(c0, std::min(c0 + kMaxChain, t));
@@ -261,7 +270,7 @@ class Builder {
         i64 distinct = 0;
         for (size_t k = 0; k < src.size(); ++k) distinct += (k == 0 || src[k].pos != src[k - 1].pos);
         // long source lists always take the matrix-core path: it is pipelined and can be split over wavefronts
-        const int rc = distinct >= kSplitSources ? 16 : class_of(rows);
+        const int rc = distinct >= split_sources_ ? 16 : class_of(rows);
         const i64 b = (i64)P_.hdr.size();
         BlockHeader h{rc, 0, tri ? 1 : 0, 0, (i64)P_.src_idx.size(), (i64)P_.coef.size()};
         for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? dest[r] : kNone);
@@ -394,7 +403,7 @@ class Builder {
         // a wavefront runs at most max_blocks_ dependent blocks back to back: every block costs a chain of dependent
         // global loads (header, ids, rows), so longer tasks stretch the level they run in
         // blocks with many sources are split over the wavefronts of a workgroup on the device: a task of their own
-        const bool wide = distinct_sources(src_) >= kSplitSources;
+        const bool wide = distinct_sources(src_) >= split_sources_;
         const bool fits = !wide && cur_task_ >= 0 && task_nblk_[cur_task_] < max_blocks_;
         i64 level;
         if (fits && need <= task_level_[cur_task_] && (chained || need == task_level_[cur_task_])) {
@@ -441,11 +450,11 @@ class Builder {
         std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
         i64 ns = 0;
         for (size_t k = 0; k < src.size(); ++k) ns += (k == 0 || src[k].pos != src[k - 1].pos);
-        if (ns <= kMaxBlockSources) {
+        if (ns <= max_block_sources_) {
             push_block(rows, dest, init, src, id_of, nullptr, level, true);
             return level;
         }
-        const i64 parts = (ns + kMaxBlockSources - 1) / kMaxBlockSources;
+        const i64 parts = (ns + max_block_sources_ - 1) / max_block_sources_;
         const i64 per = (ns + parts - 1) / parts;
         std::vector<int32_t> pdest((size_t)parts * rows);
         std::vector<Triple> chunk;
@@ -583,7 +592,7 @@ class Builder {
         constexpr int NC = BlockProgram::kClasses;
         auto task_class = [&](i64 t) {
             const BlockHeader &h = P_.hdr[task_first_blk_[t]];
-            if (task_nblk_[t] == 1 && h.rc == 16 && h.nsrc >= kSplitSources) return h.nsrc > 4 * kSplitSources ? 3 : 2;
+            if (task_nblk_[t] == 1 && h.rc == 16 && h.nsrc >= split_sources_) return h.nsrc > split8_sources_ ? 3 : 2;
             for (i64 b = task_first_blk_[t]; b < task_first_blk_[t] + task_nblk_[t]; ++b)
                 if (P_.hdr[b].rc == 16) return 1;
             return 0;
@@ -621,6 +630,7 @@ class Builder {
     const GatherForm &G_;
     const i64 n_, max_blocks_;
     const int slots_;
+    i64 split_sources_ = kSplitSources, split8_sources_ = 4 * kSplitSources, big_chain_ = kBigChain, max_block_sources_ = kMaxBlockSources;
     BlockProgram P_;
     std::vector<int32_t> avail_, task_of_, cluster_of_, slot_;
     std::vector<i64> stamp_, mark_;
