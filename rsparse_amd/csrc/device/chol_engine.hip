@@ -4,7 +4,6 @@
 #include <climits>
 
 #include "chol_engine.hpp"
-#include "chol_kernels.hip"
 
 namespace rsp {
 
@@ -111,21 +110,18 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     }
     const i64 npairs = (i64)pairs.size();
     if (npairs >= INT32_MAX) return kBadInput;
-    std::vector<i64> tgt_ptr(npanels_ + 1, 0);
-    for (const Pair &p : pairs) tgt_ptr[p.s + 1]++;
-    for (i64 s = 0; s < npanels_; ++s) tgt_ptr[s + 1] += tgt_ptr[s];
-    std::vector<int32_t> by_target(npairs);
+    // position in the target panel of every row a pair updates: rel[rel_off + (q - q0)], q = q0 .. |R_d| - 1
+    std::vector<i64> rel_off(npairs + 1, 0);
+    for (i64 k = 0; k < npairs; ++k) rel_off[k + 1] = rel_off[k] + (prow[pairs[k].d] - pairs[k].q0);
+    std::vector<int32_t> rel((size_t)rel_off[npairs]);
     {
+        std::vector<i64> tgt_ptr(npanels_ + 1, 0);
+        for (const Pair &p : pairs) tgt_ptr[p.s + 1]++;
+        for (i64 s = 0; s < npanels_; ++s) tgt_ptr[s + 1] += tgt_ptr[s];
+        std::vector<int32_t> by_target(npairs);
         std::vector<i64> fill(tgt_ptr.begin(), tgt_ptr.end() - 1);
-        for (i64 k = 0; k < npairs; ++k) by_target[fill[pairs[k].s]++] = (int32_t)k;  // ascending d inside a target
-    }
-
-    // ---- slots (panel, position) and their tuple lists ------------------------------------------
-    std::vector<i64> slot_base(npanels_ + 1, 0);
-    for (i64 s = 0; s < npanels_; ++s) slot_base[s + 1] = slot_base[s] + (c0[s + 1] - c0[s]) + prow[s];
-    const i64 nslots_all = slot_base[npanels_];
-    std::vector<int32_t> tcount(nslots_all, 0), posmap(n_, -1);
-    auto for_each_tuple = [&](auto &&fn) {
+        for (i64 k = 0; k < npairs; ++k) by_target[fill[pairs[k].s]++] = (int32_t)k;
+        std::vector<int32_t> posmap(n_, -1);
         for (i64 s = 0; s < npanels_; ++s) {
             if (tgt_ptr[s] == tgt_ptr[s + 1]) continue;
             const i64 w = c0[s + 1] - c0[s];
@@ -133,41 +129,53 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             const i64 *Rs = R(s);
             for (i64 k = 0; k < prow[s]; ++k) posmap[Rs[k]] = (int32_t)(w + k);
             for (i64 k = tgt_ptr[s]; k < tgt_ptr[s + 1]; ++k) {
-                const Pair &p = pairs[by_target[k]];
+                const i64 pk = by_target[k];
+                const Pair &p = pairs[pk];
                 const i64 *Rd = R(p.d);
-                for (i64 q = p.q0; q < prow[p.d]; ++q) fn(s, slot_base[s] + posmap[Rd[q]], by_target[k], q);
+                for (i64 q = p.q0; q < prow[p.d]; ++q) {
+                    const int32_t pos = posmap[Rd[q]];
+                    // every row below a column of L(:, d) that lies in panel s is a row of panel s (column structure
+                    // of a Cholesky factor); anything else means parent/cp do not describe this pattern
+                    if (pos < 0 || (Rd[q] >= c0[s + 1] && (pos < w || Rs[pos - w] != Rd[q]))) return kBadInput;
+                    rel[(size_t)(rel_off[pk] + (q - p.q0))] = pos;
+                }
             }
         }
-    };
-    i64 ntuples = 0;
-    for_each_tuple([&](i64, i64 slot, int32_t, i64) { tcount[slot]++; ++ntuples; });
-    // active slots in level order
-    std::vector<int32_t> slot_panel, slot_pos, active(nslots_all, -1);
-    std::vector<i64> slot_tptr(1, 0);
+    }
+    std::vector<dev::CholPair> pair_rec(npairs);
+    for (i64 k = 0; k < npairs; ++k) {
+        const Pair &p = pairs[k];
+        dev::CholPair &r = pair_rec[k];
+        r.src_base = Lp_[c0[p.d]];
+        r.tgt_base = Lp_[c0[p.s]];
+        r.rel_off = rel_off[k];
+        r.wd = c0[p.d + 1] - c0[p.d];
+        r.len_d = r.wd + prow[p.d];
+        r.len_s = (c0[p.s + 1] - c0[p.s]) + prow[p.s];
+        r.q0 = p.q0;
+        r.mask = p.mask;
+        r.rd = prow[p.d];
+    }
+    std::vector<i64> pair_ptr(npanels_ + 1, 0);  // pairs were generated source by source
+    for (const Pair &p : pairs) pair_ptr[p.d + 1]++;
+    for (i64 d = 0; d < npanels_; ++d) pair_ptr[d + 1] += pair_ptr[d];
+    std::vector<dev::CholPanel> panel_rec(npanels_);
+    for (i64 s = 0; s < npanels_; ++s) panel_rec[s] = dev::CholPanel{Lp_[c0[s]], c0[s + 1] - c0[s], prow[s]};
+
+    // ---- per level: factor items, row-solve items of the tall panels, update items of the level's panels ------
     levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0});
-    std::vector<int32_t> item_panel, item_block, multi;
+    std::vector<int32_t> item_panel, item_block, multi, upd_pair, upd_q;
     for (i64 l = 0; l < nlevels_; ++l) {
-        levels_[l].slot_begin = (i64)slot_panel.size();
         levels_[l].item_begin = (i64)item_panel.size();
         multi.clear();
         for (i64 k = lv_ptr[l]; k < lv_ptr[l + 1]; ++k) {
             const i64 s = lv_panels[k];
-            const i64 rows = slot_base[s + 1] - slot_base[s];
-            for (i64 pos = 0; pos < rows; ++pos) {
-                const i64 slot = slot_base[s] + pos;
-                if (tcount[slot] == 0) continue;
-                active[slot] = (int32_t)slot_panel.size();
-                slot_panel.push_back((int32_t)s);
-                slot_pos.push_back((int32_t)pos);
-                slot_tptr.push_back(slot_tptr.back() + tcount[slot]);
-            }
             // panels with <= 64 rows below the diagonal block are finished by one wavefront (block 0); larger ones
             // get a diagonal-only item (block -1) now and their row blocks in a second launch
             item_panel.push_back((int32_t)s);
             item_block.push_back(prow[s] <= 64 ? 0 : -1);
             if (prow[s] > 64) multi.push_back((int32_t)s);
         }
-        levels_[l].slot_count = (i64)slot_panel.size() - levels_[l].slot_begin;
         levels_[l].item_count = (i64)item_panel.size() - levels_[l].item_begin;
         levels_[l].trsm_begin = (i64)item_panel.size();
         for (int32_t s : multi)
@@ -176,23 +184,19 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
                 item_block.push_back((int32_t)b);
             }
         levels_[l].trsm_count = (i64)item_panel.size() - levels_[l].trsm_begin;
+        levels_[l].upd_begin = (i64)upd_pair.size();
+        for (i64 k = lv_ptr[l]; k < lv_ptr[l + 1]; ++k) {
+            const i64 d = lv_panels[k];
+            for (i64 pk = pair_ptr[d]; pk < pair_ptr[d + 1]; ++pk)
+                for (i64 q = pairs[pk].q0; q < prow[d]; q += 16) {
+                    upd_pair.push_back((int32_t)pk);
+                    upd_q.push_back((int32_t)q);
+                }
+        }
+        levels_[l].upd_count = (i64)upd_pair.size() - levels_[l].upd_begin;
     }
-    std::vector<int32_t> tuple_pair(ntuples), tuple_q(ntuples);
-    {
-        std::vector<i64> fill(slot_tptr.begin(), slot_tptr.end() - 1);
-        for_each_tuple([&](i64, i64 slot, int32_t pair, i64 q) {
-            const i64 at = fill[active[slot]]++;
-            tuple_pair[at] = pair;
-            tuple_q[at] = (int32_t)q;
-        });
-    }
-    std::vector<int32_t> pair_src(npairs), pair_q0(npairs);
-    std::vector<uint32_t> pair_mask(npairs);
-    for (i64 k = 0; k < npairs; ++k) {
-        pair_src[k] = pairs[k].d;
-        pair_q0[k] = pairs[k].q0;
-        pair_mask[k] = pairs[k].mask;
-    }
+    if (upd_pair.size() >= (size_t)INT32_MAX) return kBadInput;
+    update_items_ = (i64)upd_pair.size();
 
     // ---- uploads ----------------------------------------------------------------------------------
     d_Lp.upload(Lp_);
@@ -201,15 +205,11 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     d_Ax.resize((size_t)annz_);
     d_Adst.upload(Adst);
     d_panel_c0.upload(c0);
-    d_panel_rows.upload(prow);
-    d_slot_panel.upload(slot_panel);
-    d_slot_pos.upload(slot_pos);
-    d_slot_tptr.upload(slot_tptr);
-    d_tuple_pair.upload(tuple_pair);
-    d_tuple_q.upload(tuple_q);
-    d_pair_src.upload(pair_src);
-    d_pair_q0.upload(pair_q0);
-    d_pair_mask.upload(pair_mask);
+    d_panels.upload(panel_rec);
+    d_pairs.upload(pair_rec);
+    d_rel.upload(rel);
+    d_upd_pair.upload(upd_pair);
+    d_upd_q.upload(upd_q);
     d_item_panel.upload(item_panel);
     d_item_block.upload(item_block);
     d_status.resize(1);
@@ -233,21 +233,18 @@ int CholFactor::factorize(const CscView &A)
     if (annz_)
         hipLaunchKernelGGL(dev::chol_scatter_A, dim3((unsigned)((annz_ + 255) / 256)), dim3(256), 0, stream, d_Ax.get(),
                            d_Adst.get(), annz_, d_Lx.get());
-    const dev::CholUpdateArgs U{d_slot_panel.get(), d_slot_pos.get(), d_slot_tptr.get(), d_tuple_pair.get(),
-                                d_tuple_q.get(),    d_pair_src.get(), d_pair_q0.get(),   d_pair_mask.get(),
-                                d_panel_c0.get(),   d_Lp.get(),       d_Lx.get()};
-    const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panel_c0.get(), d_panel_rows.get(),
-                                d_Lp.get(),         d_Lx.get(),         d_status.get()};
+    const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get()};
+    const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get()};
     for (const Level &lv : levels_) {
-        if (lv.slot_count)
-            hipLaunchKernelGGL(dev::chol_panel_update, dim3((unsigned)((lv.slot_count + 3) / 4)), dim3(256), 0, stream, U,
-                               lv.slot_begin, lv.slot_count);
         if (lv.item_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4)), dim3(256), 0, stream, F,
                                lv.item_begin, lv.item_count, 0);
         if (lv.trsm_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.trsm_count + 3) / 4)), dim3(256), 0, stream, F,
                                lv.trsm_begin, lv.trsm_count, 1);
+        if (lv.upd_count)  // the level's panels are final: subtract their outer products from their ancestors
+            hipLaunchKernelGGL(dev::chol_rank_update, dim3((unsigned)((lv.upd_count + 3) / 4)), dim3(256), 0, stream, U,
+                               lv.upd_begin, lv.upd_count);
     }
     RSP_HIP(hipEventRecord(ev1, stream));
     RSP_HIP(hipGetLastError());

@@ -1,16 +1,17 @@
 // Numeric sparse Cholesky on the GPU (rsparse::chol, /root/reference/src/lib.rs:278-337).
 //
 // The reference is up-looking and strictly sequential in the row index.  Here the same factor is
-// produced by a supernodal LEFT-looking schedule: columns are grouped into panels (fundamental supernodes
-// cut to at most kPanelWidth columns), panels are levelled by the elimination tree, and each level is two
-// kernel launches:
-//   1. update  : every (panel, row) pair owned by exactly one wavefront gathers the contributions
-//                - sum_u L(row,u) L(col,u) of all descendant panels  (atomics-free, deterministic order)
-//   2. factor  : dense Cholesky of the panel's diagonal block + triangular solve of the rows below it
+// produced by a supernodal RIGHT-looking schedule: columns are grouped into panels (fundamental supernodes
+// cut to at most kPanelWidth columns), panels are levelled by the elimination tree, and each level is up to
+// three kernel launches:
+//   1. factor  : dense Cholesky of the panel's diagonal block + triangular solve of the rows below it
+//   2. update  : every factored panel subtracts its outer product from the ancestor panels it touches
+//                (16 x 32 tiles on the matrix cores, f64 atomics into L)
 // The pattern of L (Lp == cp, diagonal first, rows ascending) is computed on the host exactly as the
 // reference lays it out, so the integer structure is bit-identical; values agree to rounding.
 #pragma once
 #include "engine.hpp"
+#include "chol_kernels.hip"
 
 namespace rsp {
 
@@ -47,24 +48,21 @@ class CholFactor {
     // device: scatter of A into L
     DeviceBuffer<double> d_Ax;    // nnz(A)
     DeviceBuffer<i64> d_Adst;     // nnz(A): destination entry of L, or -1
-    // device: panels
-    DeviceBuffer<int32_t> d_panel_c0;   // npanels+1
-    DeviceBuffer<int32_t> d_panel_rows; // npanels: rows below the panel (r)
-    // update programme: slots (panel,row position), tuples (pair, q), pairs (source panel, q0, column mask)
-    DeviceBuffer<int32_t> d_slot_panel, d_slot_pos;  // per active slot
-    DeviceBuffer<i64> d_slot_tptr;                    // per active slot + 1
-    DeviceBuffer<int32_t> d_tuple_pair, d_tuple_q;
-    DeviceBuffer<int32_t> d_pair_src, d_pair_q0;
-    DeviceBuffer<uint32_t> d_pair_mask;
-    // factor programme: work items (panel, row block)
-    DeviceBuffer<int32_t> d_item_panel, d_item_block;
+    // device: panels, update pairs (source panel -> ancestor panel) and the per-level work items
+    DeviceBuffer<int32_t> d_panel_c0;         // npanels+1
+    DeviceBuffer<dev::CholPanel> d_panels;    // npanels
+    DeviceBuffer<dev::CholPair> d_pairs;
+    DeviceBuffer<int32_t> d_rel;              // per pair: position in the target panel of every updated row
+    DeviceBuffer<int32_t> d_upd_pair, d_upd_q;  // update items: (pair, first row of the 16-row tile)
+    DeviceBuffer<int32_t> d_item_panel, d_item_block;  // factor items: (panel, row block)
     DeviceBuffer<int32_t> d_status;  // [0] = smallest column with a non-positive pivot, or INT_MAX
     struct Level {
-        i64 slot_begin, slot_count;  // update work (active slots)
         i64 item_begin, item_count;  // factor work: whole small panels + diagonal blocks of large ones
         i64 trsm_begin, trsm_count;  // second launch: row blocks of the large panels
+        i64 upd_begin, upd_count;    // third launch: rank updates from this level's panels
     };
     std::vector<Level> levels_;
+    i64 update_items_ = 0;
 
     std::unique_ptr<TriSolver> lower_, upper_;
     DeviceBuffer<double> work_;

@@ -1,15 +1,23 @@
-// HIP kernels (gfx950) for the supernodal left-looking numeric Cholesky (see chol_engine.hpp).
+// HIP kernels (gfx950) for the supernodal right-looking numeric Cholesky (see chol_engine.hpp).
 //
 // Storage is the reference's CSC layout of L itself (Lp == cp, diagonal first, rows ascending), so the
 // result needs no conversion.  A panel is a run of <= 32 consecutive columns c0..c1-1 with the supernode
 // property  rows(col c0+t) = {c0+t, .., c1-1} U R  (R = rows below the panel, shared by all its columns).
 // "Position" pos of a row in the panel: pos = row - c0 inside the diagonal block, w + index-in-R below it.
-// Entry (pos, t) of the panel lives at  Lx[Lp[c0+t] + pos - t]   (pos >= t).
+// Column c0+t holds len0 - t entries (len0 = w + |R|), so with base = Lp[c0]
+//     entry (pos, t)  lives at  Lx[base + t*len0 - t(t-1)/2 + pos - t]        (pos >= t)
+// -- a closed form: no kernel below ever chases Lp through memory.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace rsp {
 namespace dev {
+
+__device__ __forceinline__ int64_t panel_entry(int64_t base, int len0, int pos, int t)
+{
+    return base + (int64_t)t * len0 - (int64_t)((t * (t - 1)) >> 1) + (pos - t);
+}
 
 // L = 0 was memset; place the entries of triu(P A P') (duplicates resolved on the host: dst < 0 = ignored)
 __global__ __launch_bounds__(256) void chol_scatter_A(const double *__restrict__ Ax, const int64_t *__restrict__ dst, int64_t nnz,
@@ -21,61 +29,108 @@ __global__ __launch_bounds__(256) void chol_scatter_A(const double *__restrict__
     if (d >= 0) Lx[d] = Ax[e];
 }
 
+// ---- rank update: a factored panel d subtracts its outer product from every ancestor panel it touches -----------
+// For a pair (d -> s) the rows of R_d that are columns of s are R_d[q0 .. q0 + ncols) (bit t of `mask`: column
+// c0_s + t), and the update is
+//     L_s(row R_d[q], col R_d[q0 + j])  -=  sum_u L_d(q, u) * L_d(q0 + j, u)        for q >= q0 + j.
+// One wavefront owns (pair, 16 consecutive q): a 16 x (<= 32) tile on the matrix cores (v_mfma_f64_16x16x4_f64:
+// A = the 16 rows q, B = the <= 32 rows q0 + j, K = the panel's <= 32 columns), every operand fetched in ONE
+// round trip, then subtracted from L_s with hardware f64 atomics: several panels of one level may update the same
+// entry, and the order in which their contributions arrive is not fixed (results agree to rounding, like any other
+// summation order; the pattern and everything integer stay exact).
+struct CholPair {        // 48 bytes
+    int64_t src_base;    // Lp[c0_d]
+    int64_t tgt_base;    // Lp[c0_s]
+    int64_t rel_off;     // into rel: position in panel s of R_d[q], q = q0 ...
+    int32_t wd, len_d;   // source panel: columns, len0
+    int32_t len_s;       // target panel: len0
+    int32_t q0;
+    uint32_t mask;
+    int32_t rd;          // |R_d|
+};
+
 struct CholUpdateArgs {
-    const int32_t *slot_panel;  // active slots of this launch
-    const int32_t *slot_pos;
-    const int64_t *slot_tptr;   // tuples of slot a: [slot_tptr[a], slot_tptr[a+1])
-    const int32_t *tuple_pair;
-    const int32_t *tuple_q;
-    const int32_t *pair_src;    // source panel d
-    const int32_t *pair_q0;     // first row of R_d that lies in the target panel
-    const uint32_t *pair_mask;  // bit t set: column c0_target + t is a row of R_d
-    const int32_t *panel_c0;
-    const int64_t *Lp;
+    const int32_t *item_pair;  // work items of all levels: (pair, first q of the tile)
+    const int32_t *item_q;
+    const CholPair *pairs;
+    const int32_t *rel;
     double *Lx;
 };
 
-// One wavefront per (target panel s, row position pos).  Lane l serves target column t = l & 31; the two
-// half-waves split the columns u of each source panel.  For every descendant panel d that contains this row
-// (tuple = (pair d->s, index q of the row in R_d)):
-//     acc[t] += sum_u L_d(q, u) * L_d(qq(t), u)        qq(t) = index in R_d of column c0_s + t, if present, qq <= q
-// and finally L_s(pos, t) -= acc[t].  Each entry of L is written by exactly one lane of one wavefront of the
-// launch: no atomics, and the summation order is fixed by the host-built tuple order.
-__global__ __launch_bounds__(256) void chol_panel_update(CholUpdateArgs A, int64_t slot_begin, int64_t nslots)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_t item_begin, int64_t nitems)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t a =
-        slot_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (a >= slot_begin + nslots) return;
-    const int s = A.slot_panel[a], pos = A.slot_pos[a];
-    const int c0s = A.panel_c0[s], ws = A.panel_c0[s + 1] - c0s;
-    const int t = lane & 31, half = lane >> 5;
-    const uint32_t below = (1u << t) - 1u;
-    double acc = 0.0;
-    const int64_t tend = A.slot_tptr[a + 1];
-    for (int64_t tp = A.slot_tptr[a]; tp < tend; ++tp) {
-        const int pr = A.tuple_pair[tp], q = A.tuple_q[tp];
-        const int d = A.pair_src[pr], q0 = A.pair_q0[pr];
-        const uint32_t mask = A.pair_mask[pr];
-        const int c0d = A.panel_c0[d], wd = A.panel_c0[d + 1] - c0d;
-        const int qq = q0 + __popc(mask & below);
-        const bool active = ((mask >> t) & 1u) && qq <= q;
-        for (int u = half; u < wd; u += 2) {
-            const int64_t base = A.Lp[c0d + u] + (wd - u);  // first entry of R_d in column c0d+u
-            const double lq = A.Lx[base + q];
-            if (active) acc += lq * A.Lx[base + qq];
+    const int64_t it =
+        item_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (it >= item_begin + nitems) return;
+    const int pr = A.item_pair[it], qt = A.item_q[it];
+    const CholPair P = A.pairs[pr];
+    const int g = lane >> 4, j = lane & 15;
+    const int ncols = __popc(P.mask);
+    const int ksteps = (P.wd + 3) >> 2;  // wave-uniform
+    const bool two = ncols > 16;
+
+    // one round trip: A rows (q = qt + j), B rows (q0 + j, q0 + 16 + j), target positions of this lane's 4 rows
+    double a[8], b0[8], b1[8];
+    const int qa = qt + j, qb0 = P.q0 + j, qb1 = P.q0 + 16 + j;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = b0[k] = b1[k] = 0.0;
+        if (k < ksteps) {
+            const int u = 4 * k + g;
+            const bool col = u < P.wd;
+            if (col && qa < P.rd) a[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qa, u)];
+            if (col && j < ncols) b0[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qb0, u)];
+            if (two && col && 16 + j < ncols) b1[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qb1, u)];
         }
     }
-    acc += __shfl_xor(acc, 32, 64);
-    if (half == 0 && t < ws && t <= pos) A.Lx[A.Lp[c0s + t] + pos - t] -= acc;
+    int relpos[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int q = qt + 4 * s + g;
+        relpos[s] = q < P.rd ? A.rel[P.rel_off + (q - P.q0)] : 0;
+    }
+    // target column of this lane in each column tile: the (j)-th and (16 + j)-th set bit of the mask
+    int t0 = 0, t1 = 0, seen = 0;
+    for (uint32_t m = P.mask; m; m &= m - 1) {  // wave-uniform loop over the set bits
+        const int t = __builtin_ctz(m);
+        if (seen == j) t0 = t;
+        if (seen == 16 + j) t1 = t;
+        ++seen;
+    }
+
+    f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < ksteps) {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b0[k], c0, 0, 0, 0);
+            if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b1[k], c1, 0, 0, 0);
+        }
+
+    // C layout: lane (g, j), register s  <->  row qt + 4s + g, column tile entry j
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int q = qt + 4 * s + g;
+        if (q >= P.rd) continue;
+        if (j < ncols && q >= P.q0 + j) unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos[s], t0), -c0[s]);
+        if (two && 16 + j < ncols && q >= P.q0 + 16 + j)
+            unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos[s], t1), -c1[s]);
+    }
 }
+
+// ---- panel factorisation -------------------------------------------------------------------------------------
+struct CholPanel {   // 16 bytes
+    int64_t base;    // Lp[c0]
+    int32_t w, r;    // columns, rows below the diagonal block
+};
 
 struct CholFactorArgs {
     const int32_t *item_panel;
     const int32_t *item_block;
+    const CholPanel *panels;
     const int32_t *panel_c0;
-    const int32_t *panel_rows;
-    const int64_t *Lp;
     double *Lx;
     int32_t *status;  // smallest column whose pivot d <= 0 (lib.rs:325)
 };
@@ -96,15 +151,32 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     if (it >= item_begin + nitems) return;
     double(*D)[33] = tiles[wv];
     const int s = A.item_panel[it], blk = A.item_block[it];
-    const int c0 = A.panel_c0[s], w = A.panel_c0[s + 1] - c0, r = A.panel_rows[s];
+    const CholPanel P = A.panels[s];
+    const int w = P.w, r = P.r, len0 = w + r;
 
-    if (lane < w)
-        for (int t = 0; t <= lane; ++t) D[lane][t] = A.Lx[A.Lp[c0 + t] + lane - t];
+    // the diagonal block and (when this item solves rows) this lane's row: all loads of one round trip
+    double dv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = 64 * k + lane, t = idx >> 5, rp = idx & 31;
+        dv[k] = (t < w && rp < w && rp >= t) ? A.Lx[panel_entry(P.base, len0, rp, t)] : 0.0;
+    }
+    const int rr = blk * 64 + lane;
+    const bool solve = blk >= 0 && rr < r;
+    const int pos = w + rr;
+    double x[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) x[t] = (solve && t < w) ? A.Lx[panel_entry(P.base, len0, pos, t)] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = 64 * k + lane;
+        D[idx & 31][idx >> 5] = dv[k];
+    }
     __builtin_amdgcn_wave_barrier();
     if (!trsm_only) {
         for (int t = 0; t < w; ++t) {
             const double dtt = D[t][t];
-            if (dtt <= 0.0 && lane == 0) atomicMin(A.status, c0 + t);
+            if (dtt <= 0.0 && lane == 0) atomicMin(A.status, A.panel_c0[s] + t);
             const double l = sqrt(dtt);
             __builtin_amdgcn_wave_barrier();
             if (lane == t) D[t][t] = l;
@@ -112,21 +184,19 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
             __builtin_amdgcn_wave_barrier();
             if (lane > t && lane < w) {
                 const double lit = D[lane][t];
-                for (int j = t + 1; j <= lane; ++j) D[lane][j] -= lit * D[j][t];
+                for (int jj = t + 1; jj <= lane; ++jj) D[lane][jj] -= lit * D[jj][t];
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane < w)
-            for (int t = 0; t <= lane; ++t) A.Lx[A.Lp[c0 + t] + lane - t] = D[lane][t];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = 64 * k + lane, t = idx >> 5, rp = idx & 31;
+            if (t < w && rp < w && rp >= t) A.Lx[panel_entry(P.base, len0, rp, t)] = D[rp][t];
+        }
         if (blk < 0) return;
     }
 
-    const int rr = blk * 64 + lane;
-    if (rr < r) {
-        const int pos = w + rr;
-        double x[32];
-#pragma unroll
-        for (int t = 0; t < 32; ++t) x[t] = (t < w) ? A.Lx[A.Lp[c0 + t] + pos - t] : 0.0;
+    if (solve) {
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
             if (t < w) {
@@ -138,7 +208,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
         }
 #pragma unroll
         for (int t = 0; t < 32; ++t)
-            if (t < w) A.Lx[A.Lp[c0 + t] + pos - t] = x[t];
+            if (t < w) A.Lx[panel_entry(P.base, len0, pos, t)] = x[t];
     }
 }
 
