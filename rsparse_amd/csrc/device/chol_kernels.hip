@@ -14,6 +14,8 @@
 namespace rsp {
 namespace dev {
 
+__device__ __forceinline__ double readlane_f64(double v, int src_lane);  // blocked_kernels.hip
+
 __device__ __forceinline__ int64_t panel_entry(int64_t base, int len0, int pos, int t)
 {
     return base + (int64_t)t * len0 - (int64_t)((t * (t - 1)) >> 1) + (pos - t);
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void chol_scatter_A(const double *__restrict__
 // c0_s + t), and the update is
 //     L_s(row R_d[q], col R_d[q0 + j])  -=  sum_u L_d(q, u) * L_d(q0 + j, u)        for q >= q0 + j.
 // One wavefront owns (pair, 16 consecutive q): a 16 x (<= 32) tile on the matrix cores (v_mfma_f64_16x16x4_f64:
-// A = the 16 rows q, B = the <= 32 rows q0 + j, K = the panel's <= 32 columns), every operand fetched in ONE
+// A = the <= 32 rows q0 + j, B = the 16 rows q, K = the panel's <= 32 columns), every operand fetched in ONE
 // round trip, then subtracted from L_s with hardware f64 atomics: several panels of one level may update the same
 // entry, and the order in which their contributions arrive is not fixed (results agree to rounding, like any other
 // summation order; the pattern and everything integer stay exact).
@@ -72,51 +74,55 @@ __global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_
     const int ksteps = (P.wd + 3) >> 2;  // wave-uniform
     const bool two = ncols > 16;
 
-    // one round trip: A rows (q = qt + j), B rows (q0 + j, q0 + 16 + j), target positions of this lane's 4 rows
-    double a[8], b0[8], b1[8];
-    const int qa = qt + j, qb0 = P.q0 + j, qb1 = P.q0 + 16 + j;
+    // one round trip: A = the rows that are target COLUMNS (q0 + j, q0 + 16 + j), B = the tile's rows (qt + j), and
+    // the target position of this lane's row
+    double a0[8], a1[8], b[8];
+    const int qr = qt + j, qc0 = P.q0 + j, qc1 = P.q0 + 16 + j;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        a[k] = b0[k] = b1[k] = 0.0;
+        a0[k] = a1[k] = b[k] = 0.0;
         if (k < ksteps) {
             const int u = 4 * k + g;
             const bool col = u < P.wd;
-            if (col && qa < P.rd) a[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qa, u)];
-            if (col && j < ncols) b0[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qb0, u)];
-            if (two && col && 16 + j < ncols) b1[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qb1, u)];
+            if (col && qr < P.rd) b[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qr, u)];
+            if (col && j < ncols) a0[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qc0, u)];
+            if (two && col && 16 + j < ncols) a1[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qc1, u)];
         }
     }
-    int relpos[4];
+    const int relpos = qr < P.rd ? A.rel[P.rel_off + (qr - P.q0)] : 0;
+    // C layout: lane (g, j), register s  <->  column number 4s + g (+ 16) of the pair, row qt + j.  One atomic
+    // instruction therefore covers 16 consecutive rows of 4 target columns: whole 128-byte runs of L_s.
+    // tc[c]: target column (bit position in the mask) of column number 4c + g, c = 0..7
+    int tc[8];
+    {
+        uint32_t m = P.mask;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int q = qt + 4 * s + g;
-        relpos[s] = q < P.rd ? A.rel[P.rel_off + (q - P.q0)] : 0;
-    }
-    // target column of this lane in each column tile: the (j)-th and (16 + j)-th set bit of the mask
-    int t0 = 0, t1 = 0, seen = 0;
-    for (uint32_t m = P.mask; m; m &= m - 1) {  // wave-uniform loop over the set bits
-        const int t = __builtin_ctz(m);
-        if (seen == j) t0 = t;
-        if (seen == 16 + j) t1 = t;
-        ++seen;
+        for (int c = 0; c < 8; ++c) {
+            tc[c] = 0;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int t = m ? __builtin_ctz(m) : 0;  // wave-uniform
+                if (gg == g) tc[c] = t;
+                m &= m - 1;
+            }
+        }
     }
 
     f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (k < ksteps) {
-            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b0[k], c0, 0, 0, 0);
-            if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b1[k], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b[k], c0, 0, 0, 0);
+            if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b[k], c1, 0, 0, 0);
         }
 
-    // C layout: lane (g, j), register s  <->  row qt + 4s + g, column tile entry j
+    if (qr >= P.rd) return;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int q = qt + 4 * s + g;
-        if (q >= P.rd) continue;
-        if (j < ncols && q >= P.q0 + j) unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos[s], t0), -c0[s]);
-        if (two && 16 + j < ncols && q >= P.q0 + 16 + j)
-            unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos[s], t1), -c1[s]);
+        const int cn = 4 * s + g;  // column number inside the pair
+        if (cn < ncols && qr >= P.q0 + cn) unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos, tc[s]), -c0[s]);
+        if (two && 16 + cn < ncols && qr >= P.q0 + 16 + cn)
+            unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos, tc[4 + s]), -c1[s]);
     }
 }
 
@@ -155,46 +161,50 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     const int w = P.w, r = P.r, len0 = w + r;
 
     // the diagonal block and (when this item solves rows) this lane's row: all loads of one round trip
-    double dv[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int idx = 64 * k + lane, t = idx >> 5, rp = idx & 31;
-        dv[k] = (t < w && rp < w && rp >= t) ? A.Lx[panel_entry(P.base, len0, rp, t)] : 0.0;
-    }
     const int rr = blk * 64 + lane;
     const bool solve = blk >= 0 && rr < r;
     const int pos = w + rr;
     double x[32];
 #pragma unroll
     for (int t = 0; t < 32; ++t) x[t] = (solve && t < w) ? A.Lx[panel_entry(P.base, len0, pos, t)] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int idx = 64 * k + lane;
-        D[idx & 31][idx >> 5] = dv[k];
-    }
-    __builtin_amdgcn_wave_barrier();
     if (!trsm_only) {
-        for (int t = 0; t < w; ++t) {
-            const double dtt = D[t][t];
-            if (dtt <= 0.0 && lane == 0) atomicMin(A.status, A.panel_c0[s] + t);
-            const double l = sqrt(dtt);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == t) D[t][t] = l;
-            if (lane > t && lane < w) D[lane][t] /= l;
-            __builtin_amdgcn_wave_barrier();
-            if (lane > t && lane < w) {
-                const double lit = D[lane][t];
-                for (int jj = t + 1; jj <= lane; ++jj) D[lane][jj] -= lit * D[jj][t];
+        // dense Cholesky of the diagonal block in registers: lane = row, d[t] = entry (lane, t); the pivot column
+        // travels by readlane, so the 32 column steps are straight-line code without a single memory access
+        double d[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) d[t] = (lane < w && t <= lane) ? A.Lx[panel_entry(P.base, len0, lane, t)] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            if (t < w) {  // wave-uniform
+                const double dtt = readlane_f64(d[t], t);
+                if (dtt <= 0.0 && lane == 0) atomicMin(A.status, A.panel_c0[s] + t);
+                const double l = sqrt(dtt);
+                d[t] = lane == t ? l : d[t] / l;  // L(k,i) = x_i / L(i,i), lib.rs:310
+#pragma unroll
+                for (int jj = t + 1; jj < 32; ++jj)
+                    if (jj < w) d[jj] -= d[t] * readlane_f64(d[t], jj);  // above the diagonal (lane < jj) this collects values nothing reads
             }
-            __builtin_amdgcn_wave_barrier();
         }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            if (lane < w && t <= lane) A.Lx[panel_entry(P.base, len0, lane, t)] = d[t];
+            if (lane < 32) D[lane][t] = d[t];
+        }
+        if (blk < 0) return;
+    } else {
+        double dv[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = 64 * k + lane, t = idx >> 5, rp = idx & 31;
-            if (t < w && rp < w && rp >= t) A.Lx[panel_entry(P.base, len0, rp, t)] = D[rp][t];
+            dv[k] = (t < w && rp < w && rp >= t) ? A.Lx[panel_entry(P.base, len0, rp, t)] : 0.0;
         }
-        if (blk < 0) return;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = 64 * k + lane;
+            D[idx & 31][idx >> 5] = dv[k];
+        }
     }
+    __builtin_amdgcn_wave_barrier();
 
     if (solve) {
 #pragma unroll
