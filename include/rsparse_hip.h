@@ -138,6 +138,14 @@ void rsp_chol_free(rsp_chol *F);
 
 /* rsparse::cholsol (src/lib.rs:377-389): b overwritten with A\b */
 int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
+/* cholsol over `nsys` systems that share ONE pattern (A->p, A->i; A->x is ignored) and differ in their values:
+ * Ax_all[s * nnz .. ) are the values of system s in A's entry order, B[s * n .. ) its right-hand side, overwritten
+ * by the solution.  What the reference does by calling cholsol (lib.rs:377-389) in a loop -- BASELINE.json's batched
+ * configuration -- with the ordering and the symbolic analysis done once and every kernel launched once for the
+ * whole batch.  status (may be NULL): per system RSP_OK or RSP_NOT_POSITIVE_DEFINITE; such a system keeps its
+ * right-hand side, as cholsol returns before touching b.  Returns RSP_OK when the batch ran (with status == NULL:
+ * RSP_NOT_POSITIVE_DEFINITE if any system failed). */
+int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B, int64_t nsys, int8_t order, int32_t *status);
 
 /* ---- LU ---------------------------------------------------------------------------------------
  * rsparse::lu (src/lib.rs:519-622) runs on the host (pivot sequence must be bit-exact with the

@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     amd,
     chol,
     cholsol,
+    cholsol_batch,
     device_count,
     lib,
     lsolve,

@@ -89,6 +89,7 @@ def lib():
             "rsp_chol_factor_ms": (dbl, [vp]),
             "rsp_chol_free": (None, [vp]),
             "rsp_cholsol_f64": (cint, [csc, vp, C.c_int8]),
+            "rsp_cholsol_batch_f64": (cint, [csc, vp, vp, i64, C.c_int8, vp]),
             "rsp_lu_f64": (cint, [csc, vp, dbl, C.POINTER(vp)]),
             "rsp_lu_L": (cint, [vp, csc]),
             "rsp_lu_U": (cint, [vp, csc]),
@@ -274,6 +275,21 @@ def cholsol(a, b, order):
     a = _as_sprs(a)
     assert b.dtype == np.float64 and b.flags.c_contiguous
     _check(lib().rsp_cholsol_f64(C.byref(a._view()), b.ctypes.data, order))
+
+
+def cholsol_batch(a, values, B, order):
+    """cholsol (src/lib.rs:377) for every system of a batch that shares the pattern of `a`.
+
+    values: (nsys, nnz) array, row s = the values of system s in a's entry order; B: (nsys, n), overwritten by the
+    solutions.  Returns an int32 array of per-system status (0 = ok, 1 = NotPositiveDefinite, right-hand side kept).
+    """
+    a = _as_sprs(a)
+    nsys = values.shape[0]
+    assert values.dtype == np.float64 and values.flags.c_contiguous and values.shape == (nsys, int(a.p[-1]))
+    assert B.dtype == np.float64 and B.flags.c_contiguous and B.shape == (nsys, a.n)
+    status = np.zeros(nsys, np.int32)
+    _check(lib().rsp_cholsol_batch_f64(C.byref(a._view()), values.ctypes.data, B.ctypes.data, nsys, order, status.ctypes.data))
+    return status
 
 
 class LuHandle:

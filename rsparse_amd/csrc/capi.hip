@@ -1,6 +1,8 @@
 // extern "C" surface of librsparse_hip.so (declared in include/rsparse_hip.h).
 // Nothing throws across this boundary: every entry point maps exceptions to an rsp_status.
+#include <climits>
 #include <cstring>
+#include <utility>
 #include <new>
 
 #include "../../include/rsparse_hip.h"
@@ -358,6 +360,52 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     rsp_chol_free(F);
     rsp_symb_free(S);
     return st;
+}
+
+int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B, int64_t nsys, int8_t order, int32_t *status)
+{
+    if (!sane_indices(A) || A->m != A->n || nsys < 0 || (nsys > 0 && (!Ax_all || !B))) return RSP_BAD_INPUT;
+    if (nsys == 0 || A->n == 0) return RSP_OK;
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        const int64_t n = A->n, nnz = A->p[n];
+        const Symbolic S = symbolic_cholesky(view_of(A), order);  // one ordering and one analysis for the whole batch
+        CholFactor F;
+        if (int st = F.analyze(view_of(A), S)) return st;
+        bool any_bad = false;
+        std::vector<int32_t> bad;
+        std::vector<double> keep((size_t)n);
+        if (n > kBatchMaxN) {  // too large for the LDS-resident solve: one system at a time through the ordinary path
+            for (int64_t s = 0; s < nsys; ++s) {
+                CscView V = view_of(A);
+                V.x = Ax_all + s * nnz;
+                const int st = F.factorize(V);
+                if (st == kOk) F.solve_host(B + s * n, n, 1);
+                else if (st != kNotPositiveDefinite) return st;
+                if (status) status[s] = st;
+                any_bad = any_bad || st != kOk;
+            }
+            return (!status && any_bad) ? (int)RSP_NOT_POSITIVE_DEFINITE : (int)RSP_OK;
+        }
+        // chunks bounded by device memory for the factors (8 GiB) and by the grid's second dimension
+        const int64_t per = std::max<int64_t>(1, std::min<int64_t>(32768, (int64_t)(8ll << 30) / (8 * std::max<int64_t>(1, F.lnz()))));
+        for (int64_t s0 = 0; s0 < nsys; s0 += per) {
+            const int64_t cnt = std::min(per, nsys - s0);
+            bad.assign((size_t)cnt, 0);
+            F.factorize_values(Ax_all + s0 * nnz, cnt, bad.data());
+            // a system that is not positive definite keeps its right-hand side (cholsol returns before touching b, lib.rs:380)
+            std::vector<std::pair<int64_t, std::vector<double>>> saved;
+            for (int64_t s = 0; s < cnt; ++s)
+                if (bad[s] != INT_MAX) saved.emplace_back(s, std::vector<double>(B + (s0 + s) * n, B + (s0 + s + 1) * n));
+            F.solve_batch(B + s0 * n, cnt);
+            for (auto &sv : saved) std::copy(sv.second.begin(), sv.second.end(), B + (s0 + sv.first) * n);
+            for (int64_t s = 0; s < cnt; ++s) {
+                if (status) status[s0 + s] = bad[s] == INT_MAX ? RSP_OK : RSP_NOT_POSITIVE_DEFINITE;
+                any_bad = any_bad || bad[s] != INT_MAX;
+            }
+        }
+        return (!status && any_bad) ? (int)RSP_NOT_POSITIVE_DEFINITE : (int)RSP_OK;
+    });
 }
 
 // ---- LU -----------------------------------------------------------------------------------------

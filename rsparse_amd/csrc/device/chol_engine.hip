@@ -219,44 +219,115 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
 int CholFactor::factorize(const CscView &A)
 {
     if (A.n != n_ || A.nnz() != annz_) return kBadInput;
+    int32_t bad = INT_MAX;
+    factorize_values(A.x, 1, &bad);
+    return bad == INT_MAX ? kOk : kNotPositiveDefinite;
+}
+
+// nsys systems with the analysed pattern and the values Ax_all[s * nnz(A) ...]; first_bad[s] = smallest column of
+// system s with a pivot <= 0, or INT_MAX.  All systems go through the same launches (grid.y = system).
+void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first_bad)
+{
     lower_.reset();
     upper_.reset();
+    batch_ = nsys;
     hipStream_t stream = nullptr;
     hipEvent_t ev0, ev1;
     RSP_HIP(hipEventCreate(&ev0));
     RSP_HIP(hipEventCreate(&ev1));
-    if (annz_) RSP_HIP(hipMemcpyAsync(d_Ax.get(), A.x, (size_t)annz_ * sizeof(double), hipMemcpyHostToDevice, stream));
-    const int32_t none = INT_MAX;
-    RSP_HIP(hipMemcpyAsync(d_status.get(), &none, sizeof(none), hipMemcpyHostToDevice, stream));
+    d_Lx.resize((size_t)lnz_ * (size_t)nsys);
+    d_Ax.resize((size_t)annz_ * (size_t)nsys);
+    d_status.resize((size_t)nsys);
+    if (annz_) RSP_HIP(hipMemcpyAsync(d_Ax.get(), Ax_all, (size_t)annz_ * (size_t)nsys * sizeof(double), hipMemcpyHostToDevice, stream));
+    RSP_HIP(hipMemsetAsync(d_status.get(), 0x7f, (size_t)nsys * sizeof(int32_t), stream));  // 0x7f7f7f7f: "none"
     RSP_HIP(hipEventRecord(ev0, stream));
-    RSP_HIP(hipMemsetAsync(d_Lx.get(), 0, (size_t)lnz_ * sizeof(double), stream));
+    RSP_HIP(hipMemsetAsync(d_Lx.get(), 0, (size_t)lnz_ * (size_t)nsys * sizeof(double), stream));
+    const unsigned ny = (unsigned)nsys;
     if (annz_)
-        hipLaunchKernelGGL(dev::chol_scatter_A, dim3((unsigned)((annz_ + 255) / 256)), dim3(256), 0, stream, d_Ax.get(),
-                           d_Adst.get(), annz_, d_Lx.get());
+        hipLaunchKernelGGL(dev::chol_scatter_A, dim3((unsigned)((annz_ + 255) / 256), ny), dim3(256), 0, stream, d_Ax.get(),
+                           d_Adst.get(), annz_, d_Lx.get(), annz_, lnz_);
     const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get()};
     const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get()};
     for (const Level &lv : levels_) {
         if (lv.item_count)
-            hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4)), dim3(256), 0, stream, F,
-                               lv.item_begin, lv.item_count, 0);
+            hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4), ny), dim3(256), 0, stream, F,
+                               lv.item_begin, lv.item_count, 0, lnz_);
         if (lv.trsm_count)
-            hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.trsm_count + 3) / 4)), dim3(256), 0, stream, F,
-                               lv.trsm_begin, lv.trsm_count, 1);
+            hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.trsm_count + 3) / 4), ny), dim3(256), 0, stream, F,
+                               lv.trsm_begin, lv.trsm_count, 1, lnz_);
         if (lv.upd_count)  // the level's panels are final: subtract their outer products from their ancestors
-            hipLaunchKernelGGL(dev::chol_rank_update, dim3((unsigned)((lv.upd_count + 3) / 4)), dim3(256), 0, stream, U,
-                               lv.upd_begin, lv.upd_count);
+            hipLaunchKernelGGL(dev::chol_rank_update, dim3((unsigned)((lv.upd_count + 3) / 4), ny), dim3(256), 0, stream, U,
+                               lv.upd_begin, lv.upd_count, lnz_);
     }
     RSP_HIP(hipEventRecord(ev1, stream));
     RSP_HIP(hipGetLastError());
-    int32_t status = INT_MAX;
-    RSP_HIP(hipMemcpy(&status, d_status.get(), sizeof(status), hipMemcpyDeviceToHost));
+    std::vector<int32_t> status((size_t)nsys);
+    RSP_HIP(hipMemcpy(status.data(), d_status.get(), (size_t)nsys * sizeof(int32_t), hipMemcpyDeviceToHost));
     RSP_HIP(hipEventSynchronize(ev1));
     float ms = 0.f;
     RSP_HIP(hipEventElapsedTime(&ms, ev0, ev1));
     factor_ms_ = ms;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
-    return status == INT_MAX ? kOk : kNotPositiveDefinite;
+    for (i64 s = 0; s < nsys; ++s) first_bad[s] = status[s] >= n_ ? INT_MAX : status[s];
+}
+
+// cholsol solve phase for every system of the last factorize_values(): B is nsys x n on the host, overwritten.
+void CholFactor::solve_batch(double *B, i64 nsys)
+{
+    if (nsys <= 0 || n_ == 0) return;
+    if (nsys != batch_) throw DeviceError("solve_batch: not the batch that was factored");
+    if (!d_row_ptr.size()) {  // index arrays of the two sweeps, built once per pattern
+        std::vector<int32_t> li((size_t)lnz_), row_ptr(n_ + 1, 0);
+        for (i64 p = 0; p < lnz_; ++p) li[p] = (int32_t)Li_[p];
+        for (i64 j = 0; j < n_; ++j)
+            for (i64 p = Lp_[j] + 1; p < Lp_[j + 1]; ++p) row_ptr[Li_[p] + 1]++;
+        for (i64 r = 0; r < n_; ++r) row_ptr[r + 1] += row_ptr[r];
+        std::vector<int32_t> row_col((size_t)row_ptr[n_]), row_pos((size_t)row_ptr[n_]), fill(row_ptr.begin(), row_ptr.end() - 1);
+        for (i64 j = 0; j < n_; ++j)  // columns ascending: every row's entries end up in ascending column order
+            for (i64 p = Lp_[j] + 1; p < Lp_[j + 1]; ++p) {
+                const int32_t at = fill[Li_[p]]++;
+                row_col[at] = (int32_t)j;
+                row_pos[at] = (int32_t)p;
+            }
+        auto by_level = [&](const std::vector<int32_t> &lev, std::vector<int32_t> &ptr, std::vector<int32_t> &items) {
+            int32_t nl = 0;
+            for (int32_t l : lev) nl = std::max(nl, l + 1);
+            ptr.assign(nl + 1, 0);
+            for (int32_t l : lev) ptr[l + 1]++;
+            for (int32_t l = 0; l < nl; ++l) ptr[l + 1] += ptr[l];
+            items.resize(lev.size());
+            std::vector<int32_t> f(ptr.begin(), ptr.end() - 1);
+            for (size_t k = 0; k < lev.size(); ++k) items[f[lev[k]]++] = (int32_t)k;
+            return nl;
+        };
+        std::vector<int32_t> lev(n_, 0), ptr, items;
+        for (i64 r = 0; r < n_; ++r)
+            for (int32_t e = row_ptr[r]; e < row_ptr[r + 1]; ++e) lev[r] = std::max(lev[r], lev[row_col[e]] + 1);
+        nlev_l_ = by_level(lev, ptr, items);
+        d_lev_ptr_l.upload(ptr);
+        d_lev_rows_l.upload(items);
+        std::fill(lev.begin(), lev.end(), 0);
+        for (i64 j = n_ - 1; j >= 0; --j)
+            for (i64 p = Lp_[j] + 1; p < Lp_[j + 1]; ++p) lev[j] = std::max(lev[j], lev[Li_[p]] + 1);
+        nlev_t_ = by_level(lev, ptr, items);
+        d_lev_ptr_t.upload(ptr);
+        d_lev_cols_t.upload(items);
+        d_Li32.upload(li);
+        d_row_ptr.upload(row_ptr);
+        d_row_col.upload(row_col);
+        d_row_pos.upload(row_pos);
+        RSP_HIP(hipFuncSetAttribute((const void *)dev::chol_batch_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kBatchMaxN * 8)));
+    }
+    DeviceBuffer<double> dB((size_t)nsys * (size_t)n_);
+    RSP_HIP(hipMemcpy(dB.get(), B, (size_t)nsys * (size_t)n_ * sizeof(double), hipMemcpyHostToDevice));
+    const dev::CholBatchSolveArgs S{d_Lp.get(),        d_Li32.get(),       d_row_ptr.get(),    d_row_col.get(),
+                                    d_row_pos.get(),   d_lev_ptr_l.get(),  d_lev_rows_l.get(), d_lev_ptr_t.get(),
+                                    d_lev_cols_t.get(), has_pinv_ ? d_pinv.get() : nullptr, d_Lx.get(), dB.get(),
+                                    lnz_,              (int32_t)n_,        nlev_l_,            nlev_t_};
+    hipLaunchKernelGGL(dev::chol_batch_solve, dim3((unsigned)nsys), dim3(256), (size_t)n_ * 8, nullptr, S);
+    RSP_HIP(hipGetLastError());
+    RSP_HIP(hipMemcpy(B, dB.get(), (size_t)nsys * (size_t)n_ * sizeof(double), hipMemcpyDeviceToHost));
 }
 
 void CholFactor::download(i64 *Lp, i64 *Li, double *Lx) const

@@ -16,6 +16,7 @@
 namespace rsp {
 
 constexpr int kPanelWidth = 32;
+constexpr i64 kBatchMaxN = 16384;  // batched solve keeps the vector of a system in LDS (128 KiB)
 
 class CholFactor {
    public:
@@ -23,6 +24,10 @@ class CholFactor {
     int analyze(const CscView &A, const Symbolic &S);
     // numeric factorisation of values A.x (same pattern as analysed). kOk / kNotPositiveDefinite.
     int factorize(const CscView &A);
+    // batched variant (same pattern, nsys value sets): see chol_engine.hip.  n must not exceed kBatchMaxN for solve_batch.
+    void factorize_values(const double *Ax_all, i64 nsys, int32_t *first_bad);
+    void solve_batch(double *B, i64 nsys);
+    i64 annz() const { return annz_; }
     void solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool permute, hipStream_t stream);
     void solve_host(double *B, i64 ldb, i64 nrhs);
     void download(i64 *Lp, i64 *Li, double *Lx) const;
@@ -63,6 +68,10 @@ class CholFactor {
     };
     std::vector<Level> levels_;
     i64 update_items_ = 0;
+    // batched solve phase: CSR index of L and the level sets of both sweeps
+    i64 batch_ = 1;
+    int32_t nlev_l_ = 0, nlev_t_ = 0;
+    DeviceBuffer<int32_t> d_Li32, d_row_ptr, d_row_col, d_row_pos, d_lev_ptr_l, d_lev_rows_l, d_lev_ptr_t, d_lev_cols_t;
 
     std::unique_ptr<TriSolver> lower_, upper_;
     DeviceBuffer<double> work_;

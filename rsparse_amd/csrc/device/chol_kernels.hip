@@ -22,13 +22,15 @@ __device__ __forceinline__ int64_t panel_entry(int64_t base, int len0, int pos, 
 }
 
 // L = 0 was memset; place the entries of triu(P A P') (duplicates resolved on the host: dst < 0 = ignored)
+// Every kernel of the factorisation takes a batch dimension: blockIdx.y = system, all systems share the pattern
+// (and therefore every index array) and differ in their values only: Ax + y * ax_stride, Lx + y * lx_stride.
 __global__ __launch_bounds__(256) void chol_scatter_A(const double *__restrict__ Ax, const int64_t *__restrict__ dst, int64_t nnz,
-                                                      double *__restrict__ Lx)
+                                                      double *__restrict__ Lx, int64_t ax_stride, int64_t lx_stride)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
     const int64_t d = dst[e];
-    if (d >= 0) Lx[d] = Ax[e];
+    if (d >= 0) Lx[(int64_t)blockIdx.y * lx_stride + d] = Ax[(int64_t)blockIdx.y * ax_stride + e];
 }
 
 // ---- rank update: a factored panel d subtracts its outer product from every ancestor panel it touches -----------
@@ -61,8 +63,9 @@ struct CholUpdateArgs {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_t item_begin, int64_t nitems)
+__global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_t item_begin, int64_t nitems, int64_t lx_stride)
 {
+    A.Lx += (int64_t)blockIdx.y * lx_stride;
     const int lane = threadIdx.x & 63;
     const int64_t it =
         item_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
@@ -148,8 +151,11 @@ struct CholFactorArgs {
 //   block == -1                : panel with more rows: factor the diagonal block and write it back, nothing else;
 //   trsm_only == 1 (next launch): load the already factored block and solve rows [64*block, 64*block + 64).
 // Row solve: lane = one row below the block,  x <- x * D^-T  (L(k,i) = x_i / L(i,i), lib.rs:310).
-__global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64_t item_begin, int64_t nitems, int trsm_only)
+__global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64_t item_begin, int64_t nitems, int trsm_only,
+                                                         int64_t lx_stride)
 {
+    A.Lx += (int64_t)blockIdx.y * lx_stride;
+    A.status += blockIdx.y;  // one status word per system
     __shared__ double tiles[4][32][33];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -220,6 +226,56 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
         for (int t = 0; t < 32; ++t)
             if (t < w) A.Lx[panel_entry(P.base, len0, pos, t)] = x[t];
     }
+}
+
+// ---- batched cholsol solve phase: many small systems with one pattern --------------------------------------------
+// One workgroup per system; the vector lives in LDS for the whole of  x = P b, L x = b, L' x = b, b = P' x
+// (lib.rs:383-386).  Both sweeps are level-scheduled gathers (one thread per unknown of the level, a workgroup
+// barrier between levels): lsolve reads row r of L through a CSR index built once on the host (columns ascending:
+// the same subtraction order as the reference's column sweep), ltsolve reads column j of the CSC as it is.
+struct CholBatchSolveArgs {
+    const int64_t *Lp;        // n + 1 (diagonal first in every column)
+    const int32_t *Li;        // lnz, row of every entry
+    const int32_t *row_ptr;   // n + 1: strictly-lower entries of row r ...
+    const int32_t *row_col;   // ... their columns (ascending) ...
+    const int32_t *row_pos;   // ... and their positions in Lx
+    const int32_t *lev_ptr_l, *lev_rows_l;  // lsolve: rows by level
+    const int32_t *lev_ptr_t, *lev_cols_t;  // ltsolve: columns by level
+    const int64_t *pinv;      // may be null
+    const double *Lx;
+    double *B;                // nsys x n
+    int64_t lx_stride;
+    int32_t n, nlev_l, nlev_t;
+};
+
+__global__ __launch_bounds__(256) void chol_batch_solve(CholBatchSolveArgs A)
+{
+    extern __shared__ double xs[];
+    const double *Lx = A.Lx + (int64_t)blockIdx.x * A.lx_stride;
+    double *b = A.B + (int64_t)blockIdx.x * A.n;
+    const int tid = threadIdx.x, n = A.n;
+    for (int k = tid; k < n; k += 256) xs[A.pinv ? A.pinv[k] : k] = b[k];  // ipvec, lib.rs:2151
+    __syncthreads();
+    for (int l = 0; l < A.nlev_l; ++l) {
+        for (int k = A.lev_ptr_l[l] + tid; k < A.lev_ptr_l[l + 1]; k += 256) {
+            const int r = A.lev_rows_l[k];
+            double acc = xs[r];
+            for (int e = A.row_ptr[r]; e < A.row_ptr[r + 1]; ++e) acc -= Lx[A.row_pos[e]] * xs[A.row_col[e]];
+            xs[r] = acc / Lx[A.Lp[r]];
+        }
+        __syncthreads();
+    }
+    for (int l = 0; l < A.nlev_t; ++l) {
+        for (int k = A.lev_ptr_t[l] + tid; k < A.lev_ptr_t[l + 1]; k += 256) {
+            const int j = A.lev_cols_t[k];
+            const int64_t p0 = A.Lp[j], p1 = A.Lp[j + 1];
+            double acc = xs[j];
+            for (int64_t p = p0 + 1; p < p1; ++p) acc -= Lx[p] * xs[A.Li[p]];
+            xs[j] = acc / Lx[p0];
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < n; k += 256) b[k] = xs[A.pinv ? A.pinv[k] : k];  // pvec, lib.rs:2244
 }
 
 }  // namespace dev

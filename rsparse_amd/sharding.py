@@ -76,3 +76,18 @@ def solve_sharded(solve_block, B, dst, device, dist):
     if c:
         mine = solve_block(mine)
     return gather_columns(mine, B.shape[1], dst, device, dist)
+
+
+def solve_batch_sharded(solve_systems, values, B, dst, device, dist):
+    """Batched independent systems (one pattern, `values[s]` / `B[s]` per system, present on every rank): rank r takes
+    the contiguous range column_block(nsys, world, r) and runs `solve_systems(values_block, B_block) -> X_block` on
+    it (on a GPU box: rsparse_amd.cholsol_batch); no rank needs anything from another one.  The (nsys, n) solution is
+    assembled on rank `dst`, None elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nsys = B.shape[0]
+    s, c = column_block(nsys, world, rank)
+    mine = np.ascontiguousarray(B[s:s + c].copy())
+    if c:
+        mine = solve_systems(np.ascontiguousarray(values[s:s + c]), mine)
+    out = gather_columns(np.asfortranarray(mine.T), nsys, dst, device, dist)
+    return None if out is None else np.ascontiguousarray(out.T)

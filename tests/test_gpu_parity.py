@@ -268,3 +268,53 @@ def test_empty_and_tiny():
     b = np.array([3.0])
     rs.lsolve(A, b)
     assert b[0] == 0.75
+
+
+# ---- batched cholsol: many systems, one pattern (BASELINE.json's batched configuration) -----------------
+
+def _circuit_batch(n, nsys, topology_seed=6):
+    mats = [synth.circuit_spd(n, topology_seed, 100 + s) for s in range(nsys)]
+    p, i = mats[0][2], mats[0][3]
+    assert all(np.array_equal(m[2], p) and np.array_equal(m[3], i) for m in mats)  # shared pattern
+    values = np.ascontiguousarray(np.stack([m[4] for m in mats]))
+    B = np.ascontiguousarray(np.stack([synth.splitmix64(1000 + s, n) for s in range(nsys)]))
+    return mats, values, B
+
+
+@pytest.mark.parametrize("n,order", [(300, 0), (300, -1), (2000, 0)])
+def test_cholsol_batch_vs_oracle(n, order):
+    mats, values, B = _circuit_batch(n, 6)
+    want = []
+    for s, A in enumerate(mats):
+        st, x = orc.cholsol(A, B[s].copy(), order)
+        assert st == orc.OK
+        want.append(x)
+    got = B.copy()
+    status = rs.cholsol_batch(mats[0], values, got, order)
+    assert status.tolist() == [0] * len(mats)
+    for s, A in enumerate(mats):
+        assert rel_inf(got[s], want[s]) <= REL_X
+        r = orc.gaxpy(A, got[s], -B[s])
+        assert np.linalg.norm(r) / np.linalg.norm(B[s]) <= REL_RES
+
+
+def test_cholsol_batch_matches_single_calls_and_flags_bad_systems():
+    mats, values, B = _circuit_batch(400, 5)
+    values[3, mats[0][2][17]:mats[0][2][18]] *= -1.0  # system 3: column 17 gets a negative diagonal
+    got = B.copy()
+    status = rs.cholsol_batch(mats[0], values, got, 0)
+    assert status.tolist() == [0, 0, 0, 1, 0]
+    assert np.array_equal(got[3], B[3])  # cholsol returns NotPositiveDefinite before it touches b (lib.rs:380)
+    for s in (0, 1, 2, 4):
+        one = B[s].copy()
+        rs.cholsol(mats[s], one, 0)
+        assert rel_inf(got[s], one) <= 1e-12
+
+
+def test_cholsol_batch_empty_and_single():
+    mats, values, B = _circuit_batch(64, 1)
+    got = B.copy()
+    assert rs.cholsol_batch(mats[0], values, got, 0).tolist() == [0]
+    st, want = orc.cholsol(mats[0], B[0].copy(), 0)
+    assert rel_inf(got[0], want) <= REL_X
+    assert rs.cholsol_batch(mats[0], values[:0], got[:0], 0).tolist() == []

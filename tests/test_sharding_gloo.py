@@ -81,3 +81,45 @@ def test_world_size_2_sharded_solve_matches_single_process(tmp_path, nrhs):
     got = np.load(tmp_path / "X.npy")
     assert np.array_equal(got, want)                       # same arithmetic per column: bit-identical
     assert np.array_equal(np.load(tmp_path / "Lx.npy"), np.load(tmp_path / "Lx1.npy"))  # the broadcast factor
+
+
+def _batch_worker(rank, world, port, nsys, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mats = [synth.circuit_spd(40, 6, 100 + s) for s in range(nsys)]
+    values = np.stack([m[4] for m in mats])
+    B = np.stack([synth.splitmix64(1000 + s, 40) for s in range(nsys)])
+    pattern = mats[0]
+
+    def solve_systems(vals, rhs):  # the CPU oracle stands in for cholsol_batch on this rank's GPU
+        for k in range(rhs.shape[0]):
+            A = (pattern[0], pattern[1], pattern[2], pattern[3], vals[k])
+            st, rhs[k] = orc.cholsol(A, rhs[k].copy(), 0)
+            assert st == orc.OK
+        return rhs
+
+    X = sharding.solve_batch_sharded(solve_systems, values, B, 0, torch.device("cpu"), dist)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "Xb.npy"), X)
+    else:
+        assert X is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nsys", [1, 5, 8])
+def test_world_size_2_sharded_batch_matches_single_process(tmp_path, nsys):
+    import torch.multiprocessing as mp
+    from oracle import pyoracle as orc
+    port = _free_port()
+    mp.spawn(_batch_worker, args=(2, port, nsys, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "Xb.npy")
+    for s in range(nsys):
+        A = synth.circuit_spd(40, 6, 100 + s)
+        st, want = orc.cholsol(A, synth.splitmix64(1000 + s, 40), 0)
+        assert np.array_equal(got[s], want)

@@ -1,0 +1,141 @@
+"""Measure the other BASELINE.json configurations (C3, C4, C5) on one GPU; one JSON line per configuration.
+
+usage: python tools/configs.py c3 [side]   3-D 7-point Laplacian side^3 (BASELINE: 80), cholesky + lsolve/ltsolve on 256 RHS
+       python tools/configs.py c4 [n]      banded-random unsymmetric (BASELINE: 200000), host lu + lsolve/usolve
+       python tools/configs.py c5 [count]  `count` circuit systems n = 2000 (BASELINE: 4096), cholsol one by one
+       python tools/configs.py c5b [count] the same systems (shared topology) through cholsol_batch
+Inputs come from rsparse_amd.synth (SplitMix64), results are checked by a residual.
+"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import rsparse_amd as rs  # noqa: E402
+from rsparse_amd import synth  # noqa: E402
+
+
+def bytes_trisolve(n, nnz, k):
+    return nnz * 12 + (n + 1) * 4 + 2 * n * k * 8
+
+
+def spmv(A, x):
+    y = np.zeros_like(x)
+    p, i, v = A.p, A.i.astype(np.int64), A.x
+    cols = np.repeat(np.arange(A.n), np.diff(p))
+    np.add.at(y, i, v * x[cols])
+    return y
+
+
+def timed_pair(first, second, n, nrhs, steps=5):
+    dev = torch.device("cuda:0")
+    X = torch.rand((n, nrhs), dtype=torch.float64, device=dev) * 2 - 1
+    stream = torch.cuda.current_stream().cuda_stream
+    rs.solve_pair_dev(first, second, X.data_ptr(), nrhs, nrhs, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    X.uniform_(-1, 1)
+    e0.record()
+    for _ in range(steps):
+        rs.solve_pair_dev(first, second, X.data_ptr(), nrhs, nrhs, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def c3(side):
+    out = {"config": "C3", "side": side}
+    A = rs.Sprs.from_tuple(synth.laplacian_3d(side))
+    t0 = time.time(); S = rs.schol(A, 0); out["schol_host_s"] = round(time.time() - t0, 2)
+    t0 = time.time(); F = rs.CholHandle(A, S); out["chol_analyze_plus_factor_s"] = round(time.time() - t0, 2)
+    fi = F.info()
+    out.update(n=fi["n"], nnz_L=fi["lnz"], chol_factor_ms=round(fi["factor_ms"], 2),
+               chol_TFLOPs=round(fi["flops"] / fi["factor_ms"] / 1e9, 3), chol_levels=fi["chol_levels"])
+    # one right-hand side through the whole cholsol solve phase, checked by the residual
+    rng = np.random.default_rng(3)
+    xs = rng.uniform(-1, 1, A.n)
+    b = spmv(A, xs)
+    x = b.copy()
+    t0 = time.time(); F.solve(x); out["first_solve_s_incl_tri_analysis"] = round(time.time() - t0, 2)
+    out["x_error_1rhs"] = float(np.max(np.abs(x - xs)))
+    L = F.factor()
+    lo, up = rs.TriHandle(L, 0), rs.TriHandle(L, 1)
+    ms = timed_pair(lo, up, A.n, 256)
+    by = 2 * bytes_trisolve(A.n, fi["lnz"], 256)
+    out.update(pair_256rhs_ms=round(ms, 3), trisolve_GBps=round(by / ms / 1e6, 1), pct_of_8TBps=round(by / ms / 1e6 / 80, 2),
+               lsolve_launches=lo.info().get("launches"), ltsolve_launches=up.info().get("launches"))
+    print(json.dumps(out), flush=True)
+
+
+def c4(n):
+    out = {"config": "C4", "n": n}
+    A = rs.Sprs.from_tuple(synth.banded_unsymmetric(n))
+    t0 = time.time(); S = rs.sqr(A, 1); out["sqr_host_s"] = round(time.time() - t0, 2)
+    t0 = time.time(); N = rs.lu(A, S, 1.0); out["lu_host_s"] = round(time.time() - t0, 2)
+    L, U = N.l, N.u
+    out.update(nnz_L=int(L.p[-1]), nnz_U=int(U.p[-1]))
+    rng = np.random.default_rng(5)
+    b = rng.uniform(0, 1, n)
+    x = b.copy()
+    t0 = time.time(); N.solve(x); out["first_solve_s_incl_tri_analysis"] = round(time.time() - t0, 2)
+    r = spmv(A, x) - b
+    out["residual_rel"] = float(np.linalg.norm(r) / np.linalg.norm(b))
+    lo, up = rs.TriHandle(L, 0), rs.TriHandle(U, 2)
+    for k in (1, 256):
+        ms = timed_pair(lo, up, n, k)
+        by = bytes_trisolve(n, int(L.p[-1]), k) + bytes_trisolve(n, int(U.p[-1]), k)
+        out[f"pair_{k}rhs_ms"] = round(ms, 3)
+        out[f"trisolve_{k}rhs_GBps"] = round(by / ms / 1e6, 1)
+    print(json.dumps(out), flush=True)
+
+
+def c5(count):
+    out = {"config": "C5", "systems": count, "n": 2000}
+    t_all = time.time()
+    worst = 0.0
+    for s in range(count):
+        A = rs.Sprs.from_tuple(synth.circuit_spd(2000, 6, 100 + s))
+        rng = np.random.default_rng(1000 + s)
+        b = rng.uniform(0, 1, A.n)
+        x = b.copy()
+        rs.cholsol(A, x, 0)
+        if s < 8:
+            worst = max(worst, float(np.linalg.norm(spmv(A, x) - b) / np.linalg.norm(b)))
+    out["cholsol_total_s"] = round(time.time() - t_all, 2)
+    out["systems_per_s"] = round(count / (time.time() - t_all), 1)
+    out["residual_rel_max_first8"] = worst
+    print(json.dumps(out), flush=True)
+
+
+def c5_batch(count):
+    """C5 variant A (shared topology, per-system values) through cholsol_batch: one analysis, one launch sequence."""
+    out = {"config": "C5-batch", "systems": count, "n": 2000}
+    t0 = time.time()
+    mats = [synth.circuit_spd(2000, 6, 100 + s) for s in range(count)]
+    values = np.ascontiguousarray(np.stack([m[4] for m in mats]))
+    B = np.ascontiguousarray(np.stack([np.random.default_rng(1000 + s).uniform(0, 1, 2000) for s in range(count)]))
+    out["generate_s"] = round(time.time() - t0, 2)
+    A0 = rs.Sprs.from_tuple(mats[0])
+    X = B[:8].copy()
+    rs.cholsol_batch(A0, values[:8], X, 0)  # warm-up: library load, first kernel launches
+    X = B.copy()
+    t0 = time.time()
+    status = rs.cholsol_batch(A0, values, X, 0)
+    dt = time.time() - t0
+    out.update(cholsol_batch_s=round(dt, 3), systems_per_s=round(count / dt, 1), failed=int(status.sum()))
+    worst = 0.0
+    for s in range(0, count, max(1, count // 8)):
+        A = rs.Sprs.from_tuple(mats[s])
+        worst = max(worst, float(np.linalg.norm(spmv(A, X[s]) - B[s]) / np.linalg.norm(B[s])))
+    out["residual_rel_max_sampled"] = worst
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    arg = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    {"c3": lambda: c3(arg or 80), "c4": lambda: c4(arg or 200000), "c5": lambda: c5(arg or 4096),
+     "c5b": lambda: c5_batch(arg or 4096)}[which]()
