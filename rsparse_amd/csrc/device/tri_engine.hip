@@ -1,6 +1,7 @@
 // TriSolver: uploads a triangular factor in execution order and runs the level-scheduled kernels.
 #include <cstdio>
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 #include "engine.hpp"
@@ -10,16 +11,24 @@
 
 namespace rsp {
 
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int TriSolver::analyze(const CscView &T, int kind)
 {
+    const double t0 = now_s();
     const int st = build_gather_form(T, kind, G_);
     if (st != kOk) return st;
+    const double t1 = now_s();
     n_ = G_.n;
     nnz_ = (i64)G_.idx.size() + n_;
     // canonical level sets (reported through rsp_tri_levels for bit-exact comparison)
     Schedule S = build_schedule(G_, 0);
     level_of_row_ = std::move(S.level_of_row);
     num_row_levels_ = S.num_row_levels;
+    if (getenv("RSP_TIMING")) fprintf(stderr, "tri analyze: gather form %.2fs, level sets %.2fs\n", t1 - t0, now_s() - t1);
     return kOk;
 }
 
@@ -99,7 +108,9 @@ static i64 env_or(const char *name, i64 fallback)
 
 void TriSolver::build_blocked()
 {
+    const double tb0 = now_s();
     BlockProgram P = build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots));
+    const double tb1 = now_s();
     BlockedProgram &D = blocked_;
     D.ntasks = (i64)P.task_ptr.size() - 1;
     D.nlevels = (i64)P.level_ptr.size() - 1;
@@ -154,6 +165,7 @@ void TriSolver::build_blocked()
     D.groups.upload(P.groups);
     RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * (D.cluster_slots * 512 + 1024)));
+    if (getenv("RSP_TIMING")) fprintf(stderr, "tri programme: build %.2fs, upload %.2fs\n", tb1 - tb0, now_s() - tb1);
 }
 
 void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)

@@ -10,6 +10,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <thread>
 
 #include "sparse.hpp"
 
@@ -19,6 +22,28 @@ namespace {
 constexpr int32_t kNone = BlockProgram::kNone;
 
 // 1, 2, 4: vector path (registers per lane); more than 4 unknowns: a 16-row matrix-core block (MFMA 16x16x4 f64)
+// worker threads for the O(w^3) inverses: RSP_HOST_THREADS, else OMP_NUM_THREADS (the GPU boxes set it to their CPU
+// share), else the hardware's count capped at 16
+inline i64 host_threads()
+{
+    for (const char *name : {"RSP_HOST_THREADS", "OMP_NUM_THREADS"})
+        if (const char *e = std::getenv(name))
+            if (std::atoll(e) > 0) return std::min<i64>(std::atoll(e), 64);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max<i64>(1, std::min<i64>(hw ? hw : 1, 16));
+}
+
+struct StageClock {  // RSP_TIMING=1: where the host time of a programme build goes (stderr)
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(int k)
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    }
+};
+
 inline int class_of(i64 rows) { return rows <= 1 ? 1 : rows <= 2 ? 2 : rows <= 4 ? 4 : 16; }
 
 struct Triple {
@@ -26,6 +51,13 @@ struct Triple {
     int32_t slot;  // row slot inside the block
     double val;
 };
+
+inline void sort_triples(std::vector<Triple> &src)  // by (pos, slot); most callers hand over sorted lists
+{
+    auto less = [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; };
+    if (!std::is_sorted(src.begin(), src.end(), less)) std::sort(src.begin(), src.end(), less);
+}
+
 
 class Builder {
    public:
@@ -48,7 +80,9 @@ class Builder {
 
     BlockProgram run()
     {
+        clock_.lap(7);
         if (slots_ >= 2) select_clusters();
+        clock_.lap(0);
         std::vector<char> emitted(cluster_lo_.size(), 0);
         for (i64 t = 0; t < n_;) {
             const i64 r = row_at(t);
@@ -66,7 +100,12 @@ class Builder {
             emit_segment(t, t1);
             t = t1;
         }
+        clock_.lap(1);
         finish();
+        clock_.lap(2);
+        if (std::getenv("RSP_TIMING"))
+            std::fprintf(stderr, "programme build: clusters %.2fs, emission %.2fs (of which chains: matrix %.2fs, inverse %.2fs, blocks %.2fs + %.2fs), finish %.2fs\n",
+                         clock_.acc[0], clock_.acc[1], clock_.acc[3], clock_.acc[4], clock_.acc[5], clock_.acc[6], clock_.acc[2]);
         return std::move(P_);
     }
 
@@ -266,23 +305,50 @@ class Builder {
     i64 push_block(int rows, const int32_t *dest, const int32_t *init, std::vector<Triple> &src, IdOf id_of, const double *tri,
                    i64 level, bool own_task)
     {
-        std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
+        // distinct sources in ascending pos order.  Long lists (the rows of a supernode share their sources) are not
+        // sorted as triples: the distinct positions are collected through the stamp array, sorted alone (an order of
+        // magnitude fewer), and every triple then finds its source by rank.
+        bool ranked = src.size() > 64;
+        if (ranked)
+            for (const Triple &x : src)
+                if (x.pos < 0 || x.pos >= n_) { ranked = false; break; }
         i64 distinct = 0;
-        for (size_t k = 0; k < src.size(); ++k) distinct += (k == 0 || src[k].pos != src[k - 1].pos);
+        if (ranked) {
+            if (rank_.empty()) rank_.assign(n_, 0);
+            ++stamp_id_;
+            order_.clear();
+            for (const Triple &x : src)
+                if (stamp_[x.pos] != stamp_id_) {
+                    stamp_[x.pos] = stamp_id_;
+                    order_.push_back(x.pos);
+                }
+            std::sort(order_.begin(), order_.end());
+            for (size_t k = 0; k < order_.size(); ++k) rank_[order_[k]] = (int32_t)k;
+            distinct = (i64)order_.size();
+        } else {
+            sort_triples(src);
+            for (size_t k = 0; k < src.size(); ++k) distinct += (k == 0 || src[k].pos != src[k - 1].pos);
+        }
         // long source lists always take the matrix-core path: it is pipelined and can be split over wavefronts
         const int rc = distinct >= split_sources_ ? 16 : class_of(rows);
         const i64 b = (i64)P_.hdr.size();
         BlockHeader h{rc, 0, tri ? 1 : 0, 0, (i64)P_.src_idx.size(), (i64)P_.coef.size()};
         for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? dest[r] : kNone);
         for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? init[r] : kNone);
-        i64 ns = 0;
-        for (size_t k = 0; k < src.size();) {
-            const int32_t pos = src[k].pos;
-            P_.src_idx.push_back(id_of(pos));
-            const size_t base = P_.coef.size();
-            P_.coef.resize(base + rc, 0.0);
-            for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] += src[k].val;  // duplicates add up
-            ++ns;
+        i64 ns = distinct;
+        const size_t cbase = P_.coef.size();
+        if (ranked) {
+            for (int32_t pos : order_) P_.src_idx.push_back(id_of(pos));
+            P_.coef.resize(cbase + (size_t)distinct * rc, 0.0);
+            for (const Triple &x : src) P_.coef[cbase + (size_t)rank_[x.pos] * rc + x.slot] += x.val;  // duplicates add up
+        } else {
+            for (size_t k = 0; k < src.size();) {
+                const int32_t pos = src[k].pos;
+                P_.src_idx.push_back(id_of(pos));
+                const size_t base = P_.coef.size();
+                P_.coef.resize(base + rc, 0.0);
+                for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] += src[k].val;  // duplicates add up
+            }
         }
         if (rc == 16 && ns > 0)  // the matrix-core path consumes sources sixteen at a time: pad with zero coefficients
             for (; ns % 16 != 0; ++ns) {
@@ -447,9 +513,17 @@ class Builder {
     template <class IdOf>
     i64 emit_gather(int rows, const int32_t *dest, const int32_t *init, std::vector<Triple> &src, IdOf id_of, i64 level)
     {
-        std::sort(src.begin(), src.end(), [](const Triple &a, const Triple &b) { return a.pos != b.pos ? a.pos < b.pos : a.slot < b.slot; });
+        // the common case needs the NUMBER of distinct sources only (push_block orders them itself)
+        bool in_range = true;
+        for (const Triple &x : src)
+            if (x.pos < 0 || x.pos >= n_) { in_range = false; break; }
         i64 ns = 0;
-        for (size_t k = 0; k < src.size(); ++k) ns += (k == 0 || src[k].pos != src[k - 1].pos);
+        if (in_range) {
+            ns = distinct_sources(src);
+        } else {
+            sort_triples(src);
+            for (size_t k = 0; k < src.size(); ++k) ns += (k == 0 || src[k].pos != src[k - 1].pos);
+        }
         if (ns <= max_block_sources_) {
             push_block(rows, dest, init, src, id_of, nullptr, level, true);
             return level;
@@ -457,23 +531,41 @@ class Builder {
         const i64 parts = (ns + max_block_sources_ - 1) / max_block_sources_;
         const i64 per = (ns + parts - 1) / parts;
         std::vector<int32_t> pdest((size_t)parts * rows);
-        std::vector<Triple> chunk;
-        size_t k = 0;
-        for (i64 p = 0; p < parts; ++p) {
-            chunk.clear();
-            i64 taken = 0;
-            while (k < src.size()) {
-                const bool new_src = (chunk.empty() || src[k].pos != chunk.back().pos);
-                if (new_src && taken == per) break;
-                taken += new_src;
-                chunk.push_back(src[k++]);
+        // part of a triple = rank of its source / per.  With in-range positions the ranks come from the sorted list of
+        // DISTINCT sources and the triples are bucketed in one pass; otherwise they are sorted and cut.
+        std::vector<std::vector<Triple>> chunks((size_t)parts);
+        if (in_range) {
+            if (rank_.empty()) rank_.assign(n_, 0);
+            ++stamp_id_;
+            order_.clear();
+            for (const Triple &x : src)
+                if (stamp_[x.pos] != stamp_id_) {
+                    stamp_[x.pos] = stamp_id_;
+                    order_.push_back(x.pos);
+                }
+            std::sort(order_.begin(), order_.end());
+            for (size_t k = 0; k < order_.size(); ++k) rank_[order_[k]] = (int32_t)k;
+            for (const Triple &x : src) chunks[(size_t)(rank_[x.pos] / per)].push_back(x);
+        } else {
+            sort_triples(src);
+            size_t k = 0;
+            for (i64 p = 0; p < parts; ++p) {
+                i64 taken = 0;
+                while (k < src.size()) {
+                    const bool new_src = (chunks[p].empty() || src[k].pos != chunks[p].back().pos);
+                    if (new_src && taken == per) break;
+                    taken += new_src;
+                    chunks[p].push_back(src[k++]);
+                }
             }
+        }
+        for (i64 p = 0; p < parts; ++p) {
             int32_t none[16];
             for (int r = 0; r < rows; ++r) {
                 pdest[(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
                 none[r] = kNone;
             }
-            push_block(rows, &pdest[(size_t)p * rows], p == 0 ? init : none, chunk, id_of, nullptr, level, true);
+            push_block(rows, &pdest[(size_t)p * rows], p == 0 ? init : none, chunks[p], id_of, nullptr, level, true);
         }
         // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial)
         std::vector<Triple> comb;
@@ -488,6 +580,7 @@ class Builder {
     void emit_big_chain(i64 t0, i64 t1)
     {
         close_task();
+        StageClock ck;
         const i64 w = t1 - t0;
         P_.big_chains++;
         P_.inverted_rows += w;
@@ -501,18 +594,33 @@ class Builder {
                 if (ps >= t0) M[(size_t)(t - t0) * w + (ps - t0)] += G_.val[p];
             }
         }
+        ck.lap(3);
+        // every column of the inverse is an independent forward substitution: columns are dealt round-robin to the
+        // host threads (column c costs (w - c)^2 / 2, so interleaving balances them); the result does not depend on
+        // the number of threads
         std::vector<double> Minv((size_t)w * w, 0.0);
-        std::vector<double> z(w);
-        for (i64 c = 0; c < w; ++c) {
-            z[c] = 1.0 / M[(size_t)c * w + c];
-            for (i64 r = c + 1; r < w; ++r) {
-                const double *Mr = &M[(size_t)r * w];
-                double s = 0.0;
-                for (i64 t = c; t < r; ++t) s += Mr[t] * z[t];
-                z[r] = -s / Mr[r];
+        auto invert_columns = [&](i64 first, i64 stride) {
+            std::vector<double> z(w);
+            for (i64 c = first; c < w; c += stride) {
+                z[c] = 1.0 / M[(size_t)c * w + c];
+                for (i64 r = c + 1; r < w; ++r) {
+                    const double *Mr = &M[(size_t)r * w];
+                    double s = 0.0;
+                    for (i64 t = c; t < r; ++t) s += Mr[t] * z[t];
+                    z[r] = -s / Mr[r];
+                }
+                for (i64 r = c; r < w; ++r) Minv[(size_t)r * w + c] = z[r];
             }
-            for (i64 r = c; r < w; ++r) Minv[(size_t)r * w + c] = z[r];
+        };
+        const i64 nthreads = w >= 128 ? host_threads() : 1;
+        if (nthreads <= 1) {
+            invert_columns(0, 1);
+        } else {
+            std::vector<std::thread> pool;
+            for (i64 k = 0; k < nthreads; ++k) pool.emplace_back(invert_columns, k, nthreads);
+            for (std::thread &th : pool) th.join();
         }
+        ck.lap(4);
         const i64 y0 = P_.scratch_rows;
         P_.scratch_rows += w;
         // phase A per group of 16 unknowns: all groups independent
@@ -536,7 +644,9 @@ class Builder {
                     need = std::max<i64>(need, avail_[s] + 1);
                 }
             }
+            ck.lap(5);
             const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, need);
+            ck.lap(6);
             ready = std::max(ready, done);
         }
         // phase B: X_J = Minv * Y, all groups independent
@@ -547,12 +657,12 @@ class Builder {
             int32_t dest[16], init[16];
             src_.clear();
             for (i64 t = a; t < b; ++t) {
-                const int slot = (int)(t - a);
-                dest[slot] = (int32_t)row_at(t);
-                init[slot] = kNone;
-                const double *Mi = &Minv[(size_t)(t - t0) * w];
-                for (i64 u = 0; u <= t - t0; ++u) src_.push_back(Triple{(int32_t)u, slot, -Mi[u]});
+                dest[t - a] = (int32_t)row_at(t);
+                init[t - a] = kNone;
             }
+            // generated in (source, slot) order: the sorts downstream see sorted input and skip
+            for (i64 u = 0; u < b - t0; ++u)
+                for (i64 t = std::max(a, t0 + u); t < b; ++t) src_.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u]});
             const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
             final_level = std::max(final_level, done);
         }
@@ -561,6 +671,8 @@ class Builder {
             task_of_[row_at(t)] = -2;  // never "chained" to a running task
         }
         close_task();
+        ck.lap(5);
+        for (int k = 3; k <= 6; ++k) clock_.acc[k] += ck.acc[k];
     }
 
     // ---- order tasks and clusters by level ------------------------------------------------------------------
@@ -636,6 +748,7 @@ class Builder {
     std::vector<i64> stamp_, mark_;
     i64 stamp_id_ = 0, run_id_ = 0;
     std::vector<Triple> src_;
+    std::vector<int32_t> order_, rank_;  // push_block: distinct source positions and their ranks
     std::vector<i64> cluster_lo_, cluster_hi_;
     std::vector<int32_t> cluster_level_;  // in emission order
     std::vector<int32_t> emit_order_;     // emission order -> cluster id (index into cluster_lo_)
@@ -643,6 +756,7 @@ class Builder {
     std::vector<i64> task_first_blk_, task_nblk_;
     std::vector<int32_t> task_level_;
     i64 cur_task_ = -1;
+    StageClock clock_;
 };
 
 }  // namespace
