@@ -95,18 +95,43 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
         for (i64 s = 0; s < npanels_; ++s) lv_panels[fill[plev[s]]++] = (int32_t)s;
     }
 
-    // ---- pairs (source panel d -> target panel s), bucketed by target ---------------------------
-    struct Pair { int32_t d, s, q0; uint32_t mask; };
+    // ---- update pairs (see chol_kernels.hip): inside a supernode panel by panel, between supernodes once per supernode
+    struct Pair { int32_t d, s, q0; uint32_t mask; int32_t sup, t_begin, t_end, level, atomic; };
     std::vector<Pair> pairs;
-    for (i64 d = 0; d < npanels_; ++d) {
-        const i64 *Rd = R(d);
-        const i64 rd = prow[d];
-        for (i64 q = 0; q < rd;) {
-            const int32_t s = panel_of[Rd[q]];
-            Pair p{(int32_t)d, s, (int32_t)q, 0u};
-            for (; q < rd && Rd[q] < c0[s + 1]; ++q) p.mask |= 1u << (Rd[q] - c0[s]);
-            pairs.push_back(p);
+    std::vector<int32_t> super_of_panel(npanels_), first_panel(nsuper_ + 1, 0);
+    {
+        i64 s = 0;
+        for (i64 k = 0; k < nsuper_; ++k) {
+            first_panel[k] = (int32_t)s;
+            for (; s < npanels_ && c0[s] < super[k + 1]; ++s) super_of_panel[s] = (int32_t)k;
         }
+        first_panel[nsuper_] = (int32_t)npanels_;
+    }
+    for (i64 k = 0; k < nsuper_; ++k) {
+        const i64 sc = super[k], se = super[k + 1];
+        for (i64 d = first_panel[k]; d < first_panel[k + 1]; ++d) {
+            const i64 *Rd = R(d);
+            const i64 rd = prow[d];
+            const bool last = d + 1 == first_panel[k + 1];
+            for (i64 q = 0; q < rd;) {
+                const bool inside = Rd[q] < se;  // a later column of the same supernode
+                if (!inside && !last) break;     // rows below the supernode: handled once, from its last panel
+                const int32_t s = panel_of[Rd[q]];
+                Pair p{(int32_t)d, s, (int32_t)q, 0u, (int32_t)k, 0, 0, plev[d], inside ? 0 : 1};
+                p.t_begin = inside ? (int32_t)(c0[d] - sc) : 0;
+                p.t_end = inside ? (int32_t)(c0[d + 1] - sc) : (int32_t)(se - sc);
+                for (; q < rd && Rd[q] < c0[s + 1]; ++q) p.mask |= 1u << (Rd[q] - c0[s]);
+                pairs.push_back(p);
+            }
+        }
+    }
+    {   // plain stores inside a supernode are safe only if no other supernode still updates it while its panels are
+        // being factored (true for fundamental supernodes: every other descendant hangs below the FIRST column)
+        std::vector<int32_t> incoming(nsuper_, -1);
+        for (const Pair &p : pairs)
+            if (p.atomic) incoming[super_of_panel[p.s]] = std::max(incoming[super_of_panel[p.s]], p.level);
+        for (Pair &p : pairs)
+            if (!p.atomic && incoming[p.sup] >= plev[first_panel[p.sup]]) p.atomic = 1;
     }
     const i64 npairs = (i64)pairs.size();
     if (npairs >= INT32_MAX) return kBadInput;
@@ -146,19 +171,29 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     for (i64 k = 0; k < npairs; ++k) {
         const Pair &p = pairs[k];
         dev::CholPair &r = pair_rec[k];
-        r.src_base = Lp_[c0[p.d]];
+        const i64 sc = super[p.sup];
+        r.src_base = Lp_[sc];
         r.tgt_base = Lp_[c0[p.s]];
         r.rel_off = rel_off[k];
-        r.wd = c0[p.d + 1] - c0[p.d];
-        r.len_d = r.wd + prow[p.d];
+        r.len_d = (int32_t)(Lp_[sc + 1] - Lp_[sc]);
         r.len_s = (c0[p.s + 1] - c0[p.s]) + prow[p.s];
         r.q0 = p.q0;
         r.mask = p.mask;
-        r.rd = prow[p.d];
+        r.rs = prow[p.d];
+        r.t_begin = p.t_begin;
+        r.t_end = p.t_end;
+        r.atomic = p.atomic;
+        r.pad[0] = r.pad[1] = 0;
     }
-    std::vector<i64> pair_ptr(npanels_ + 1, 0);  // pairs were generated source by source
-    for (const Pair &p : pairs) pair_ptr[p.d + 1]++;
-    for (i64 d = 0; d < npanels_; ++d) pair_ptr[d + 1] += pair_ptr[d];
+    // pairs by the level that issues them
+    std::vector<i64> pair_lv_ptr(nlevels_ + 1, 0);
+    for (const Pair &p : pairs) pair_lv_ptr[p.level + 1]++;
+    for (i64 l = 0; l < nlevels_; ++l) pair_lv_ptr[l + 1] += pair_lv_ptr[l];
+    std::vector<int32_t> pair_by_level(npairs);
+    {
+        std::vector<i64> fill(pair_lv_ptr.begin(), pair_lv_ptr.end() - 1);
+        for (i64 k = 0; k < npairs; ++k) pair_by_level[fill[pairs[k].level]++] = (int32_t)k;
+    }
     std::vector<dev::CholPanel> panel_rec(npanels_);
     for (i64 s = 0; s < npanels_; ++s) panel_rec[s] = dev::CholPanel{Lp_[c0[s]], c0[s + 1] - c0[s], prow[s]};
 
@@ -185,13 +220,12 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             }
         levels_[l].trsm_count = (i64)item_panel.size() - levels_[l].trsm_begin;
         levels_[l].upd_begin = (i64)upd_pair.size();
-        for (i64 k = lv_ptr[l]; k < lv_ptr[l + 1]; ++k) {
-            const i64 d = lv_panels[k];
-            for (i64 pk = pair_ptr[d]; pk < pair_ptr[d + 1]; ++pk)
-                for (i64 q = pairs[pk].q0; q < prow[d]; q += 16) {
-                    upd_pair.push_back((int32_t)pk);
-                    upd_q.push_back((int32_t)q);
-                }
+        for (i64 k = pair_lv_ptr[l]; k < pair_lv_ptr[l + 1]; ++k) {
+            const i64 pk = pair_by_level[k];
+            for (i64 q = pairs[pk].q0; q < prow[pairs[pk].d]; q += 16) {
+                upd_pair.push_back((int32_t)pk);
+                upd_q.push_back((int32_t)q);
+            }
         }
         levels_[l].upd_count = (i64)upd_pair.size() - levels_[l].upd_begin;
     }

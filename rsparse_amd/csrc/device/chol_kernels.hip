@@ -33,24 +33,35 @@ __global__ __launch_bounds__(256) void chol_scatter_A(const double *__restrict__
     if (d >= 0) Lx[(int64_t)blockIdx.y * lx_stride + d] = Ax[(int64_t)blockIdx.y * ax_stride + e];
 }
 
-// ---- rank update: a factored panel d subtracts its outer product from every ancestor panel it touches -----------
-// For a pair (d -> s) the rows of R_d that are columns of s are R_d[q0 .. q0 + ncols) (bit t of `mask`: column
-// c0_s + t), and the update is
-//     L_s(row R_d[q], col R_d[q0 + j])  -=  sum_u L_d(q, u) * L_d(q0 + j, u)        for q >= q0 + j.
-// One wavefront owns (pair, 16 consecutive q): a 16 x (<= 32) tile on the matrix cores (v_mfma_f64_16x16x4_f64:
-// A = the <= 32 rows q0 + j, B = the 16 rows q, K = the panel's <= 32 columns), every operand fetched in ONE
-// round trip, then subtracted from L_s with hardware f64 atomics: several panels of one level may update the same
-// entry, and the order in which their contributions arrive is not fixed (results agree to rounding, like any other
-// summation order; the pattern and everything integer stay exact).
-struct CholPair {        // 48 bytes
-    int64_t src_base;    // Lp[c0_d]
+// ---- rank update: factored columns subtract their outer product from the ancestor panels they touch --------------
+// A supernode S (W consecutive columns, rows R_S below them) is one dense trapezoid in the closed form above; a pair
+// names a range of its columns [t_begin, t_end), the rows below them (`rs` rows: the q index space, row q sits at
+// position len0_S - rs + q of S), and a target panel s: rows q0 .. q0 + ncols of the q space are columns of s (bit t of
+// `mask`: column c0_s + t).  The update is
+//     L_s(row q, column q0 + j)  -=  sum_{t in [t_begin, t_end)} L_S(q, t) * L_S(q0 + j, t)        for q >= q0 + j.
+// Two kinds of pair (host: chol_engine.hip):
+//   * INSIDE a supernode, panel by panel (t range = one panel of <= 32 columns, target = a later panel of S, issued at
+//     the panel's level): nothing else writes S while its panels are being factored, so the result is subtracted with
+//     plain loads and stores;
+//   * FROM a whole supernode to a panel of an ANCESTOR supernode (t range = all W columns, issued once S is complete):
+//     accumulated over all of S in registers and subtracted with ONE hardware f64 atomic per entry, because
+//     different supernodes of a level may update the same ancestor entry -- the only place where the order of a
+//     floating-point summation is not fixed (values agree to rounding; the integer structure is exact).
+// One wavefront owns (pair, 16 consecutive q): a 32 x 16 tile on the matrix cores (v_mfma_f64_16x16x4_f64, A = the
+// <= 32 column rows q0 + j, B = the 16 rows q, K = the t range in chunks of 32), the operands of a chunk fetched in
+// one round trip.
+struct CholPair {        // 64 bytes
+    int64_t src_base;    // Lp[first column of S]
     int64_t tgt_base;    // Lp[c0_s]
-    int64_t rel_off;     // into rel: position in panel s of R_d[q], q = q0 ...
-    int32_t wd, len_d;   // source panel: columns, len0
-    int32_t len_s;       // target panel: len0
+    int64_t rel_off;     // into rel: position in panel s of row q, q = q0 ...
+    int32_t len_d;       // len0 of S
+    int32_t len_s;       // len0 of the target panel
     int32_t q0;
     uint32_t mask;
-    int32_t rd;          // |R_d|
+    int32_t rs;          // rows of the q space
+    int32_t t_begin, t_end;
+    int32_t atomic;
+    int32_t pad[2];
 };
 
 struct CholUpdateArgs {
@@ -74,26 +85,13 @@ __global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_
     const CholPair P = A.pairs[pr];
     const int g = lane >> 4, j = lane & 15;
     const int ncols = __popc(P.mask);
-    const int ksteps = (P.wd + 3) >> 2;  // wave-uniform
     const bool two = ncols > 16;
+    const int qr = qt + j, rowbase = P.len_d - P.rs;  // position in S of row q = rowbase + q
+    const bool row_ok = qr < P.rs, col0_ok = j < ncols, col1_ok = two && 16 + j < ncols;
+    const int pos_r = rowbase + qr, pos_c0 = rowbase + P.q0 + j, pos_c1 = pos_c0 + 16;
 
-    // one round trip: A = the rows that are target COLUMNS (q0 + j, q0 + 16 + j), B = the tile's rows (qt + j), and
-    // the target position of this lane's row
-    double a0[8], a1[8], b[8];
-    const int qr = qt + j, qc0 = P.q0 + j, qc1 = P.q0 + 16 + j;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        a0[k] = a1[k] = b[k] = 0.0;
-        if (k < ksteps) {
-            const int u = 4 * k + g;
-            const bool col = u < P.wd;
-            if (col && qr < P.rd) b[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qr, u)];
-            if (col && j < ncols) a0[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qc0, u)];
-            if (two && col && 16 + j < ncols) a1[k] = A.Lx[panel_entry(P.src_base, P.len_d, P.wd + qc1, u)];
-        }
-    }
-    const int relpos = qr < P.rd ? A.rel[P.rel_off + (qr - P.q0)] : 0;
-    // C layout: lane (g, j), register s  <->  column number 4s + g (+ 16) of the pair, row qt + j.  One atomic
+    const int relpos = row_ok ? A.rel[P.rel_off + (qr - P.q0)] : 0;
+    // C layout: lane (g, j), register s  <->  column number 4s + g (+ 16) of the pair, row qt + j.  One store / atomic
     // instruction therefore covers 16 consecutive rows of 4 target columns: whole 128-byte runs of L_s.
     // tc[c]: target column (bit position in the mask) of column number 4c + g, c = 0..7
     int tc[8];
@@ -112,20 +110,44 @@ __global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_
     }
 
     f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = P.t_begin; t0 < P.t_end; t0 += 32) {  // wave-uniform
+        const int wc = min(32, P.t_end - t0);
+        const int ksteps = (wc + 3) >> 2;
+        // one round trip per chunk: A = the rows that are target COLUMNS, B = the tile's rows
+        double a0[8], a1[8], b[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (k < ksteps) {
-            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b[k], c0, 0, 0, 0);
-            if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b[k], c1, 0, 0, 0);
+        for (int k = 0; k < 8; ++k) {
+            a0[k] = a1[k] = b[k] = 0.0;
+            if (k < ksteps) {
+                const int u = 4 * k + g;
+                const bool col = u < wc;
+                if (col && row_ok) b[k] = A.Lx[panel_entry(P.src_base, P.len_d, pos_r, t0 + u)];
+                if (col && col0_ok) a0[k] = A.Lx[panel_entry(P.src_base, P.len_d, pos_c0, t0 + u)];
+                if (col && col1_ok) a1[k] = A.Lx[panel_entry(P.src_base, P.len_d, pos_c1, t0 + u)];
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ksteps) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], b[k], c0, 0, 0, 0);
+                if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k], b[k], c1, 0, 0, 0);
+            }
+    }
 
-    if (qr >= P.rd) return;
+    if (!row_ok) return;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int cn = 4 * s + g;  // column number inside the pair
-        if (cn < ncols && qr >= P.q0 + cn) unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos, tc[s]), -c0[s]);
-        if (two && 16 + cn < ncols && qr >= P.q0 + 16 + cn)
-            unsafeAtomicAdd(A.Lx + panel_entry(P.tgt_base, P.len_s, relpos, tc[4 + s]), -c1[s]);
+        if (cn < ncols && qr >= P.q0 + cn) {
+            double *dst = A.Lx + panel_entry(P.tgt_base, P.len_s, relpos, tc[s]);
+            if (P.atomic) unsafeAtomicAdd(dst, -c0[s]);
+            else *dst -= c0[s];
+        }
+        if (two && 16 + cn < ncols && qr >= P.q0 + 16 + cn) {
+            double *dst = A.Lx + panel_entry(P.tgt_base, P.len_s, relpos, tc[4 + s]);
+            if (P.atomic) unsafeAtomicAdd(dst, -c1[s]);
+            else *dst -= c1[s];
+        }
     }
 }
 
