@@ -107,20 +107,37 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
         }
         first_panel[nsuper_] = (int32_t)npanels_;
     }
+    // Inside a supernode the panels are grouped in blocks of `bp`: a panel updates the later panels of ITS block at
+    // once (32 columns at a time), the block as a whole updates the rest of the supernode when its last panel is done
+    // (32 * bp columns accumulated in registers: fewer passes over the trailing part), the supernode as a whole updates
+    // its ancestors when its last panel is done.
+    const i64 bp = std::max<i64>(1, env_or("RSP_CHOL_BLOCK_PANELS", kCholBlockPanels));
     for (i64 k = 0; k < nsuper_; ++k) {
         const i64 sc = super[k], se = super[k + 1];
         for (i64 d = first_panel[k]; d < first_panel[k + 1]; ++d) {
             const i64 *Rd = R(d);
             const i64 rd = prow[d];
-            const bool last = d + 1 == first_panel[k + 1];
+            const i64 blk0 = first_panel[k] + (d - first_panel[k]) / bp * bp;      // first panel of d's block
+            const i64 blk1 = std::min<i64>(blk0 + bp, first_panel[k + 1]);          // one past its last panel
+            const bool last_in_block = d + 1 == blk1, last = d + 1 == first_panel[k + 1];
+            const i64 block_end_col = c0[blk1];  // == se for the last block
             for (i64 q = 0; q < rd;) {
-                const bool inside = Rd[q] < se;  // a later column of the same supernode
-                if (!inside && !last) break;     // rows below the supernode: handled once, from its last panel
-                const int32_t s = panel_of[Rd[q]];
-                Pair p{(int32_t)d, s, (int32_t)q, 0u, (int32_t)k, 0, 0, plev[d], inside ? 0 : 1};
-                p.t_begin = inside ? (int32_t)(c0[d] - sc) : 0;
-                p.t_end = inside ? (int32_t)(c0[d + 1] - sc) : (int32_t)(se - sc);
-                for (; q < rd && Rd[q] < c0[s + 1]; ++q) p.mask |= 1u << (Rd[q] - c0[s]);
+                const i64 row = Rd[q];
+                Pair p{(int32_t)d, panel_of[row], (int32_t)q, 0u, (int32_t)k, 0, 0, plev[d], 0};
+                if (row < block_end_col) {          // a later panel of the same block: this panel's columns
+                    p.t_begin = (int32_t)(c0[d] - sc);
+                    p.t_end = (int32_t)(c0[d + 1] - sc);
+                } else if (row < se) {              // the rest of the supernode: the whole block, once it is complete
+                    if (!last_in_block) break;
+                    p.t_begin = (int32_t)(c0[blk0] - sc);
+                    p.t_end = (int32_t)(c0[blk1] - sc);
+                } else {                            // ancestors: the whole supernode, once it is complete
+                    if (!last) break;
+                    p.t_begin = 0;
+                    p.t_end = (int32_t)(se - sc);
+                    p.atomic = 1;
+                }
+                for (; q < rd && Rd[q] < c0[p.s + 1]; ++q) p.mask |= 1u << (Rd[q] - c0[p.s]);
                 pairs.push_back(p);
             }
         }

@@ -16,6 +16,7 @@
 namespace rsp {
 
 constexpr int kPanelWidth = 32;
+constexpr i64 kCholBlockPanels = 4;  // panels per block of the in-supernode updates (see chol_engine.hip)
 constexpr i64 kBatchMaxN = 16384;  // batched solve keeps the vector of a system in LDS (128 KiB)
 
 class CholFactor {
