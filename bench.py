@@ -118,6 +118,12 @@ def main():
             extras["cholsol_solves_per_s_1rhs"] = 1000.0 / ms
             extras["trisolve_1rhs_GBps"] = 2 * bytes_trisolve(n, info["lnz"], 1) / (ms * 1e-3) / 1e9
             del xb
+            # the literal configs[1]: ONE cholsol call from scratch (ordering, analysis, factorisation, solve, PCIe)
+            xe = b.copy()
+            t0 = time.time()
+            rs.cholsol(A, xe, 0)
+            extras["cholsol_one_shot_s"] = time.time() - t0
+            extras["cholsol_one_shot_x_error"] = float(np.max(np.abs(xe - xstar)) / np.max(np.abs(xstar)))
         fi = F.info()
         extras["chol_factor_ms"] = fi["factor_ms"]
         extras["chol_flops"] = fi["flops"]

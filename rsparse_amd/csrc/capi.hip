@@ -1,6 +1,9 @@
 // extern "C" surface of librsparse_hip.so (declared in include/rsparse_hip.h).
 // Nothing throws across this boundary: every entry point maps exceptions to an rsp_status.
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <new>
@@ -354,11 +357,19 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     if (!sane_indices(A) || !b || A->m != A->n) return RSP_BAD_INPUT;
     rsp_symb *S = nullptr;
     rsp_chol *F = nullptr;
+    const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = clock();
     int st = rsp_schol(A, order, &S);                    // ordering and symbolic analysis (host)
+    const double t1 = clock();
     if (st == RSP_OK) st = rsp_chol_factor_f64(A, S, &F);  // numeric Cholesky (GPU)
+    const double t2 = clock();
     if (st == RSP_OK) st = rsp_chol_solve_f64(F, b, A->n, 1);  // P, lsolve, ltsolve, P' (GPU)
+    const double t3 = clock();
     rsp_chol_free(F);
     rsp_symb_free(S);
+    if (getenv("RSP_TIMING"))
+        fprintf(stderr, "cholsol: schol %.2fs, chol (analysis + factor) %.2fs, solve (analysis + solve) %.2fs, free %.2fs\n", t1 - t0,
+                t2 - t1, t3 - t2, clock() - t3);
     return st;
 }
 
@@ -454,8 +465,7 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
         const int64_t n = N->f.L.n;
         if (!N->lower) {
             std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
-            if (int st = lo->analyze(N->f.L.view(), RSP_LSOLVE)) return st;
-            if (int st = up->analyze(N->f.U.view(), RSP_USOLVE)) return st;
+            if (int st = analyze_pair(*lo, N->f.L.view(), RSP_LSOLVE, *up, N->f.U.view(), RSP_USOLVE)) return st;
             N->lower = std::move(lo);
             N->upper = std::move(up);
         }

@@ -395,7 +395,7 @@ void CholFactor::build_solvers()
     d_Lx.download(Lx.data(), Lx.size());
     const CscView L{n_, n_, Lp_.data(), Li_.data(), Lx.data()};
     std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
-    if (lo->analyze(L, 0) != kOk || up->analyze(L, 1) != kOk) throw DeviceError("factor is not a valid triangular matrix");
+    if (analyze_pair(*lo, L, 0, *up, L, 1) != kOk) throw DeviceError("factor is not a valid triangular matrix");
     lower_ = std::move(lo);
     upper_ = std::move(up);
 }

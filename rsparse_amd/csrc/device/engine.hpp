@@ -130,6 +130,7 @@ class TriSolver {
     i64 algorithmic_bytes(i64 nrhs) const { return nnz_ * 12 + (n_ + 1) * 4 + 16 * n_ * nrhs; }
     // pieces of the multi-right-hand-side path that solve_pair_device drives on two streams
     void prepare_blocked(i64 total_cols);
+    void stage_blocked();  // host-only: builds the multi-RHS programme ahead of its upload
     void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy);
 
    private:
@@ -145,11 +146,14 @@ class TriSolver {
     TriProgram multi_, single_;
     BlockedProgram blocked_;
     bool have_multi_ = false, have_single_ = false, have_blocked_ = false;
+    std::unique_ptr<BlockProgram> staged_;
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
 };
 
 // first.solve then second.solve on one row-major device block, column halves pipelined over two streams
+// a.analyze(Ta, kind_a) and b.analyze(Tb, kind_b) plus both programme builds, on two host threads
+int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, const CscView &Tb, int kind_b);
 void solve_pair_device(TriSolver &first, TriSolver &second, double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
 
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)

@@ -2,6 +2,9 @@
 #include <cstdio>
 #include <algorithm>
 #include <chrono>
+#include <exception>
+#include <functional>
+#include <thread>
 #include <cstdlib>
 
 #include "engine.hpp"
@@ -106,10 +109,40 @@ static i64 env_or(const char *name, i64 fallback)
     return v && *v ? atol(v) : fallback;
 }
 
+// host half of build_blocked(): no device call, so two solvers can be staged on two host threads
+void TriSolver::stage_blocked()
+{
+    staged_.reset(new BlockProgram(
+        build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots))));
+}
+
+// analyse two factors (or one factor in two directions) side by side on two host threads, programmes included
+int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, const CscView &Tb, int kind_b)
+{
+    int sa = kOk, sb = kOk;
+    std::exception_ptr ea, eb;
+    auto work = [](TriSolver &t, const CscView &T, int kind, int &st, std::exception_ptr &e) {
+        try {
+            st = t.analyze(T, kind);
+            if (st == kOk) t.stage_blocked();
+        } catch (...) {
+            e = std::current_exception();
+        }
+    };
+    std::thread other(work, std::ref(b), std::cref(Tb), kind_b, std::ref(sb), std::ref(eb));
+    work(a, Ta, kind_a, sa, ea);
+    other.join();
+    if (ea) std::rethrow_exception(ea);
+    if (eb) std::rethrow_exception(eb);
+    return sa != kOk ? sa : sb;
+}
+
 void TriSolver::build_blocked()
 {
     const double tb0 = now_s();
-    BlockProgram P = build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots));
+    if (!staged_) stage_blocked();
+    BlockProgram P = std::move(*staged_);
+    staged_.reset();
     const double tb1 = now_s();
     BlockedProgram &D = blocked_;
     D.ntasks = (i64)P.task_ptr.size() - 1;

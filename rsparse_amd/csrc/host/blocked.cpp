@@ -612,7 +612,8 @@ class Builder {
                 for (i64 r = c; r < w; ++r) Minv[(size_t)r * w + c] = z[r];
             }
         };
-        const i64 nthreads = w >= 128 ? host_threads() : 1;
+        // starting a thread costs tens of microseconds: only chains whose inverse takes milliseconds are shared out
+        const i64 nthreads = w >= 384 ? std::min<i64>(host_threads(), w / 64) : 1;
         if (nthreads <= 1) {
             invert_columns(0, 1);
         } else {
