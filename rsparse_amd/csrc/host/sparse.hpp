@@ -161,6 +161,16 @@ struct BlockProgram {
     // pools
     std::vector<int32_t> src_idx;    // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
     std::vector<double> coef;
+    // PROLOGUE records: what a wavefront needs before it can touch X, in one contiguous piece so that it costs ONE
+    // round trip instead of two dependent ones (header, then ids).  kPrologueWords int32 per record:
+    //   [0, 8) the BlockHeader itself, [8, 24) destination ids, [24, 40) initial-value ids (first rc of each used),
+    //   [40, 56) the ids of the record's FIRST stage of 16 sources, [64, 80) those of the following stage (clamped).
+    // A block of split class 2 / 3 has 4 / 8 consecutive records, one per wavefront (its first stage is
+    // (nsrc / 16) * w / W); all other blocks have one.  block_record[b] = index of block b's first record; records
+    // follow the block order, so inside one (level, class) range they are an arithmetic sequence.
+    static constexpr int kPrologueWords = 128;
+    std::vector<int32_t> prologue;
+    std::vector<i64> block_record;   // per block, plus one past the end
     // clusters, sorted by level
     std::vector<ClusterHeader> clusters;
     std::vector<int32_t> cluster_ids;
