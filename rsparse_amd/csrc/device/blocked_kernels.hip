@@ -28,7 +28,41 @@ struct BlockArrays {
     const BlockHeader *hdr;
     const int32_t *src_idx;      // id >= 0 row of X, id < 0 scratch row ~id, INT32_MIN none
     const double *coef;
+    const int32_t *prologue;     // BlockProgram::kPrologueWords int32 per record (host/sparse.hpp)
 };
+
+// A prologue record spread over the wavefront: lane l holds words l and 64 + l.  Header, destination / initial-value ids
+// and the ids of the first stage(s) arrive in ONE round trip; after it the wavefront goes straight to the rows of X.
+struct Prologue {
+    int32_t r0, r1;
+};
+
+template <bool SECOND>
+__device__ __forceinline__ Prologue load_prologue(const BlockArrays &B, int64_t rec, int lane)
+{
+    const int32_t *p = B.prologue + rec * BlockProgram::kPrologueWords;
+    Prologue R;
+    R.r0 = p[lane];
+    R.r1 = SECOND ? p[64 + lane] : 0;
+    return R;
+}
+
+__device__ __forceinline__ BlockHeader header_of(const Prologue &R)  // wave-uniform: lives in scalar registers
+{
+    BlockHeader h;
+    h.rc = __builtin_amdgcn_readlane(R.r0, 0);
+    h.nsrc = __builtin_amdgcn_readlane(R.r0, 1);
+    h.has_tri = __builtin_amdgcn_readlane(R.r0, 2);
+    h.pad = 0;
+    h.src_off = (int64_t)(uint32_t)__builtin_amdgcn_readlane(R.r0, 4) | ((int64_t)__builtin_amdgcn_readlane(R.r0, 5) << 32);
+    h.coef_off = (int64_t)(uint32_t)__builtin_amdgcn_readlane(R.r0, 6) | ((int64_t)__builtin_amdgcn_readlane(R.r0, 7) << 32);
+    return h;
+}
+
+__device__ __forceinline__ int32_t word_at(int32_t r, int idx)  // word `idx` (0..63, per lane) of a lane-distributed vector
+{
+    return __builtin_amdgcn_ds_bpermute(idx << 2, r);
+}
 
 __device__ __forceinline__ const double *row_ptr(int32_t id, const double *X, int64_t ldx, const double *S, int64_t lds)
 {
@@ -44,24 +78,22 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)  // src_l
 
 // ---- vector path: RC <= 4 unknowns, one right-hand side per lane ---------------------------------------
 template <int RC>
-__device__ __forceinline__ void run_block_vec(const BlockHeader h, const BlockArrays &B, double *X, int64_t ldx, double *S, int64_t lds,
-                                              int col, bool live, int lane)
+__device__ __forceinline__ void run_block_vec(const BlockHeader h, const Prologue &R, const BlockArrays &B, double *X, int64_t ldx, double *S,
+                                              int64_t lds, int col, bool live, int lane)
 {
-    const int32_t *ids = B.src_idx + h.src_off;
     const double *cf = B.coef + h.coef_off;
-    const int32_t *sidx = ids + 2 * RC;
+    const int32_t *sidx = B.src_idx + h.src_off + 2 * RC;
     constexpr int SB = 16;  // sources per batch: 16 ids and 16*RC <= 64 coefficients, one vector load each
-    // round trip 2: dest / init ids (lanes 0..2RC-1), ids + coefficients of the first batch, the triangle
-    const int32_t hid = ids[lane < 2 * RC ? lane : 0];
+    // the record already holds the dest / init ids (words 8.., 24..) and the ids of the first batch (words 40..):
+    // round trip 2 fetches the rows together with the first coefficients and the triangle
     int nb = min(SB, h.nsrc);
-    int32_t idv = sidx[lane < nb ? lane : 0];
+    int32_t idv = word_at(R.r0, (40 + lane) & 63);  // lane u < 16: id of source u
     double cv = cf[lane < nb * RC ? lane : 0];
     const double tv = cf[(int64_t)h.nsrc * RC + (lane < RC * RC ? lane : 0)];  // padded pool: in bounds without a triangle
-    // round trip 3: initial values and the rows of the first batch
     double acc[RC];
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
-        const int32_t id = __builtin_amdgcn_readlane(hid, RC + r);
+        const int32_t id = __builtin_amdgcn_readlane(R.r0, 24 + r);
         acc[r] = (id != RSP_NONE && live) ? row_ptr(id, X, ldx, S, lds)[col] : 0.0;
     }
     for (int e0 = 0; e0 < h.nsrc; e0 += SB) {
@@ -100,7 +132,7 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const BlockAr
     }
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
-        const int32_t id = __builtin_amdgcn_readlane(hid, r);
+        const int32_t id = __builtin_amdgcn_readlane(R.r0, 8 + r);
         if (id != RSP_NONE && live) const_cast<double *>(row_ptr(id, X, ldx, S, lds))[col] = acc[r];
     }
 }
@@ -184,15 +216,14 @@ __device__ __forceinline__ void load_panel_tinv(PanelIds &P, const BlockHeader h
     for (int k = 0; k < 4; ++k) P.tinv[k] = tinv[k * 64 + c.lane];
 }
 
-__device__ __forceinline__ void load_panel_ids(PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c, bool lead,
-                                               bool with_tinv)
+__device__ __forceinline__ void panel_ids_from(PanelIds &P, const Prologue &R, const PanelCtx &c, bool lead)
 {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        P.dest[s] = ids[4 * s + c.g];
-        P.init[s] = lead ? ids[16 + 4 * s + c.g] : RSP_NONE;
+        P.dest[s] = word_at(R.r0, 8 + 4 * s + c.g);
+        const int32_t init = word_at(R.r0, 24 + 4 * s + c.g);
+        P.init[s] = lead ? init : RSP_NONE;
     }
-    if (with_tinv) load_panel_tinv(P, h, c);
 }
 
 // rows of the block -> acc (register s <- unknown 4s + g); kNone = zero
@@ -227,22 +258,25 @@ __device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t (
 // a stage's loads are only issued after the previous stage's MFMAs, and it is the OTHER wavefronts of the CU that
 // cover the wait -- the better trade on levels with thousands of blocks, where throughput is what counts.
 template <bool FAST, bool PIPE>
-__device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const int32_t *ids, const BlockHeader h, const PanelCtx &c,
+__device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
     const int last = st_end - 1;
     const bool any = st_begin < st_end;  // wave-uniform; a block may have no sources at all
     int32_t idA[4];
     Stage A;
-    // round trip 2
-    load_panel_ids(P, ids, h, c, lead, PIPE);
-    if (any) load_ids(idA, c, st_begin);
+    // the record holds the block's ids and those of this wavefront's first stage (and the one after it)
+    panel_ids_from(P, R, c, lead);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) idA[q] = word_at(R.r0, 40 + 4 * q + c.g);
     if (PIPE) {
         int32_t idB[4];
         Stage B;
-        if (any) load_ids(idB, c, min(st_begin + 1, last));
-        // round trip 3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) idB[q] = word_at(R.r1, 4 * q + c.g);  // used only if the wavefront has a second stage
+        // round trip 2
         panel_load_rows<FAST>(acc, P.init, c);
+        load_panel_tinv(P, h, c);
         if (!any) return;
         load_stage<FAST>(A, idA, c, st_begin);
         for (int s = st_begin; s < st_end; s += 2) {
@@ -318,13 +352,13 @@ __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArr
 }
 
 template <bool FAST, bool PIPE>
-__device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockArrays &B, double *X, int64_t ldx, double *S, int64_t lds,
-                                               int cw, int nrhs, int lane)
+__device__ __forceinline__ void run_block_mfma(const BlockHeader h, const Prologue &R, const BlockArrays &B, double *X, int64_t ldx, double *S,
+                                               int64_t lds, int cw, int nrhs, int lane)
 {
     const PanelCtx c = make_ctx(h, B, X, ldx, S, lds, cw, nrhs, lane);
     PanelIds P;
     f64x4 acc[4];
-    panel_gather<FAST, PIPE>(acc, P, B.src_idx + h.src_off, h, c, 0, h.nsrc >> 4, true);
+    panel_gather<FAST, PIPE>(acc, P, R, h, c, 0, h.nsrc >> 4, true);
     panel_finish<FAST>(acc, P, h, c, X, S);
 }
 
@@ -341,26 +375,34 @@ __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const BlockA
 struct LevelDesc {
     int64_t task_begin;      // class 0: first task
     int64_t block_begin[2];  // classes 1, 2: first block (one block per task)
+    int64_t blk0, rec0;      // class 0: first block and its prologue record (records follow the block order)
+    int64_t rec_begin[2];    // classes 1, 2: record of the first block (4 / 8 records per block)
     int ntasks, nblk[2];
     int wg0, wg1, wg2;       // workgroups per class
+    int single;              // every class-0 task is one block: block = blk0 + task, no task_ptr lookup
 };
 
-// class 0: the blocks of a task run in order
+// class 0: the blocks of a task run in order.  t = task number inside the launch.
 template <bool FAST, bool PIPE>
-__device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task, int chunk, double *X, int64_t ldx, double *S, int64_t lds,
-                                         int nrhs, int lane)
+__device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task_begin, int t, int64_t blk0, int64_t rec0, bool single, int chunk,
+                                         double *X, int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
     const int cw = chunk * 64;
     const int col = cw + lane;
     const bool live = col < nrhs;
-    const int64_t bend = B.task_ptr[task + 1];
-    for (int64_t b = B.task_ptr[task]; b < bend; ++b) {
-        const BlockHeader h = B.hdr[b];
+    int64_t b = blk0 + t, bend = b + 1;
+    if (!single) {
+        b = B.task_ptr[task_begin + t];
+        bend = B.task_ptr[task_begin + t + 1];
+    }
+    for (; b < bend; ++b) {
+        const Prologue R = load_prologue<PIPE>(B, rec0 + (b - blk0), lane);
+        const BlockHeader h = header_of(R);
         switch (h.rc) {
-            case 16: run_block_mfma<FAST, PIPE>(h, B, X, ldx, S, lds, cw, nrhs, lane); break;
-            case 1: run_block_vec<1>(h, B, X, ldx, S, lds, col, live, lane); break;
-            case 2: run_block_vec<2>(h, B, X, ldx, S, lds, col, live, lane); break;
-            default: run_block_vec<4>(h, B, X, ldx, S, lds, col, live, lane); break;
+            case 16: run_block_mfma<FAST, PIPE>(h, R, B, X, ldx, S, lds, cw, nrhs, lane); break;
+            case 1: run_block_vec<1>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            case 2: run_block_vec<2>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            default: run_block_vec<4>(h, R, B, X, ldx, S, lds, col, live, lane); break;
         }
     }
 }
@@ -378,7 +420,7 @@ __device__ __forceinline__ void split_item(int q, int n, int nchunks, int &blk, 
 // W wavefronts (w = 0..W-1) share one matrix-core block: contiguous ranges of its stages each, partial accumulators
 // meet in LDS (red: (W - 1) x 8 KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
 template <int W, bool FAST, bool PIPE>
-__device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t block, int chunk, int w, double *red, double *X,
+__device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t rec, int chunk, int w, double *red, double *X,
                                           int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
     PanelIds P;
@@ -386,10 +428,11 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
     BlockHeader h;
     PanelCtx c;
     if (valid) {
-        h = B.hdr[block];
+        const Prologue R = load_prologue<PIPE>(B, rec + w, lane);  // this wavefront's record of the block
+        h = header_of(R);
         c = make_ctx(h, B, X, ldx, S, lds, chunk * 64, nrhs, lane);
         const int nst = h.nsrc >> 4;
-        panel_gather<FAST, PIPE>(acc, P, B.src_idx + h.src_off, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
+        panel_gather<FAST, PIPE>(acc, P, R, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
         if (w > 0) {
             double *mine = red + (size_t)(w - 1) * 1024 + lane;
 #pragma unroll
@@ -414,7 +457,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
 // Levels with thousands of small-block tasks (the rows just above the clusters) are bound by how many row loads the
 // chip keeps in flight: this lean kernel (no matrix-core path, a third of the registers) runs them at 3-4x the occupancy.
 __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t task_begin, int ntasks, double *X, int64_t ldx, double *S,
-                                                         int64_t lds, int nrhs, int nchunks)
+                                                         int64_t lds, int nrhs, int nchunks, int64_t blk0, int64_t rec0, int single)
 {
     const int lane = threadIdx.x & 63;
     const int per_xcd = (int)(gridDim.x >> 3);  // XCD-aware placement as in solve_level: consecutive tasks share an XCD
@@ -424,13 +467,18 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
     if (t >= ntasks) return;
     const int col = (pair - t * nchunks) * 64 + lane;
     const bool live = col < nrhs;
-    const int64_t bend = B.task_ptr[task_begin + t + 1];
-    for (int64_t b = B.task_ptr[task_begin + t]; b < bend; ++b) {
-        const BlockHeader h = B.hdr[b];
+    int64_t b = blk0 + t, bend = b + 1;
+    if (!single) {
+        b = B.task_ptr[task_begin + t];
+        bend = B.task_ptr[task_begin + t + 1];
+    }
+    for (; b < bend; ++b) {
+        const Prologue R = load_prologue<false>(B, rec0 + (b - blk0), lane);
+        const BlockHeader h = header_of(R);
         switch (h.rc) {
-            case 1: run_block_vec<1>(h, B, X, ldx, S, lds, col, live, lane); break;
-            case 2: run_block_vec<2>(h, B, X, ldx, S, lds, col, live, lane); break;
-            default: run_block_vec<4>(h, B, X, ldx, S, lds, col, live, lane); break;
+            case 1: run_block_vec<1>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            case 2: run_block_vec<2>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            default: run_block_vec<4>(h, R, B, X, ldx, S, lds, col, live, lane); break;
         }
     }
 }
@@ -448,17 +496,17 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void solve_level(BlockArrays B, 
     if (item < L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
         int blk, chunk;
         split_item(item, L.nblk[1], nchunks, blk, chunk);
-        run_split<8, FAST, PIPE>(B, true, L.block_begin[1] + blk, chunk, w, red, X, ldx, S, lds, nrhs, lane);
+        run_split<8, FAST, PIPE>(B, true, L.rec_begin[1] + (int64_t)blk * 8, chunk, w, red, X, ldx, S, lds, nrhs, lane);
     } else if (item < L.wg2 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
         const int q = (item - L.wg2) * 2 + (w >> 2);
         const bool valid = q < L.nblk[0] * nchunks;
         int blk = 0, chunk = 0;
         if (valid) split_item(q, L.nblk[0], nchunks, blk, chunk);
-        run_split<4, FAST, PIPE>(B, valid, L.block_begin[0] + blk, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
+        run_split<4, FAST, PIPE>(B, valid, L.rec_begin[0] + (int64_t)blk * 4, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
     } else if (item < L.wg2 + L.wg1 + L.wg0) {  // 8 (task, chunk) pairs
         const int pair = (item - L.wg2 - L.wg1) * 8 + w;
         const int t = pair / nchunks;
-        if (t < L.ntasks) run_task<FAST, PIPE>(B, L.task_begin + t, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
+        if (t < L.ntasks) run_task<FAST, PIPE>(B, L.task_begin, t, L.blk0, L.rec0, L.single != 0, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
     }
 }
 

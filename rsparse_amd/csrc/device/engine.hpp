@@ -92,6 +92,8 @@ struct BlockedProgram {
     DeviceBuffer<BlockHeader> hdr;
     DeviceBuffer<int32_t> src_idx;
     DeviceBuffer<double> coef;
+    DeviceBuffer<int32_t> prologue;
+    bool single_block_tasks = false;
     DeviceBuffer<ClusterHeader> clusters;
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
@@ -99,13 +101,14 @@ struct BlockedProgram {
         i64 task_begin[4];  // by class (BlockProgram::level_class_ptr)
         int ntasks[4];
         i64 block_begin[4];  // first block of each class (split classes: one block per task)
+        i64 rec_begin[4];  // prologue record of the first block of each class
         i64 cluster_begin;
         int nclusters;
     };
     std::vector<Level> levels;
     size_t device_bytes() const
     {
-        return task_ptr.bytes() + hdr.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
+        return task_ptr.bytes() + hdr.bytes() + prologue.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
                groups.bytes();
     }
 };

@@ -165,6 +165,7 @@ void TriSolver::build_blocked()
             lv.task_begin[c] = P.level_class_ptr[NC * l + c];
             lv.ntasks[c] = (int)(P.level_class_ptr[NC * l + c + 1] - P.level_class_ptr[NC * l + c]);
             lv.block_begin[c] = P.task_ptr[lv.task_begin[c]];
+            lv.rec_begin[c] = P.block_record[lv.block_begin[c]];
         }
         D.launches += (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2] + lv.ntasks[3]) > 0;
         lv.cluster_begin = P.cluster_level_ptr[l];
@@ -190,6 +191,8 @@ void TriSolver::build_blocked()
     }
     D.task_ptr.upload(P.task_ptr);
     D.hdr.upload(P.hdr);
+    D.prologue.upload(P.prologue);
+    D.single_block_tasks = D.ntasks == D.nblocks;
     // the kernels fetch ids and coefficients a wavefront at a time (clamped lane offsets), never past these ends
     D.src_idx.upload(P.src_idx);
     D.coef.upload(P.coef);
@@ -224,7 +227,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
     const BlockedProgram &P = blocked_;
     double *const Sw = scratch_.get() ? scratch_.get() + col_off : nullptr;
     const i64 lds = total_cols;
-    const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get()};
+    const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get(), P.prologue.get()};
     const dev::ClusterArrays C{P.clusters.get(), P.cluster_ids.get(), P.groups.get()};
     // 64 right-hand sides per wavefront: 16-unknown blocks run as 4 MFMA tiles of 16 columns, small blocks one column per lane
     const int nchunks = (int)((nrhs + 63) / 64);
@@ -257,13 +260,19 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
         const bool small_alone = lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves;
         if (small_alone)
             hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)((((i64)lv.ntasks[0] * nchunks + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
-                               stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, Sw, lds, (int)nrhs, nchunks);
+                               stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, Sw, lds, (int)nrhs, nchunks, lv.block_begin[0], lv.rec_begin[0],
+                               P.single_block_tasks ? 1 : 0);
         const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
         if (n01 + lv.ntasks[2] + lv.ntasks[3]) {
             dev::LevelDesc L;
             L.task_begin = small_alone ? lv.task_begin[1] : lv.task_begin[0];
             L.block_begin[0] = lv.block_begin[2];
             L.block_begin[1] = lv.block_begin[3];
+            L.blk0 = small_alone ? lv.block_begin[1] : lv.block_begin[0];
+            L.rec0 = small_alone ? lv.rec_begin[1] : lv.rec_begin[0];
+            L.rec_begin[0] = lv.rec_begin[2];
+            L.rec_begin[1] = lv.rec_begin[3];
+            L.single = P.single_block_tasks ? 1 : 0;
             L.ntasks = n01;
             L.nblk[0] = lv.ntasks[2];
             L.nblk[1] = lv.ntasks[3];
