@@ -306,36 +306,45 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i
         second.solve_device(X, 1, ld, nrhs, stream);
         return;
     }
-    // one auxiliary stream and three events per (thread, device), created on first use and kept
+    // auxiliary streams and events per (thread, device), created on first use and kept
+    constexpr int kMaxParts = 4;
     struct Aux {
-        hipStream_t stream = nullptr;
-        hipEvent_t start = nullptr, heavy = nullptr, done = nullptr;
+        hipStream_t stream[kMaxParts] = {};
+        hipEvent_t start = nullptr, heavy[kMaxParts] = {}, done[kMaxParts] = {};
     };
     static thread_local std::vector<Aux> per_device;
+    static const i64 want_parts = std::max<i64>(2, std::min<i64>(kMaxParts, env_or("RSP_PAIR_PARTS", 2)));
     int device = 0;
     RSP_HIP(hipGetDevice(&device));
     if ((size_t)device >= per_device.size()) per_device.resize(device + 1);
     Aux &ax = per_device[device];
-    if (!ax.stream) {
-        RSP_HIP(hipStreamCreateWithFlags(&ax.stream, hipStreamNonBlocking));
+    if (!ax.start) {
         RSP_HIP(hipEventCreateWithFlags(&ax.start, hipEventDisableTiming));
-        RSP_HIP(hipEventCreateWithFlags(&ax.heavy, hipEventDisableTiming));
-        RSP_HIP(hipEventCreateWithFlags(&ax.done, hipEventDisableTiming));
+        for (int k = 0; k < kMaxParts; ++k) {
+            if (k) RSP_HIP(hipStreamCreateWithFlags(&ax.stream[k], hipStreamNonBlocking));
+            RSP_HIP(hipEventCreateWithFlags(&ax.heavy[k], hipEventDisableTiming));
+            RSP_HIP(hipEventCreateWithFlags(&ax.done[k], hipEventDisableTiming));
+        }
     }
-    const hipStream_t aux = ax.stream;
-    const hipEvent_t ev_start = ax.start, ev_heavy = ax.heavy, ev_done = ax.done;
-    const i64 na = (nchunks + 1) / 2 * 64, nb = nrhs - na;
+    // parts of whole 64-column chunks, the earlier ones one chunk larger when they do not divide evenly
+    const int parts = (int)std::min<i64>(want_parts, nchunks);
+    i64 col[kMaxParts + 1] = {0};
+    for (int k = 0; k < parts; ++k) col[k + 1] = std::min<i64>(nrhs, col[k] + (nchunks / parts + (k < nchunks % parts ? 1 : 0)) * 64);
+    col[parts] = nrhs;
     first.prepare_blocked(nrhs);   // allocations happen before anything is in flight
     second.prepare_blocked(nrhs);
-    RSP_HIP(hipEventRecord(ev_start, stream));
-    RSP_HIP(hipStreamWaitEvent(aux, ev_start, 0));
-    first.run_window(X, ld, na, 0, nrhs, stream, ev_heavy);
-    RSP_HIP(hipStreamWaitEvent(aux, ev_heavy, 0));
-    first.run_window(X + na, ld, nb, na, nrhs, aux, nullptr);
-    second.run_window(X + na, ld, nb, na, nrhs, aux, nullptr);
-    RSP_HIP(hipEventRecord(ev_done, aux));
-    second.run_window(X, ld, na, 0, nrhs, stream, nullptr);
-    RSP_HIP(hipStreamWaitEvent(stream, ev_done, 0));
+    RSP_HIP(hipEventRecord(ax.start, stream));
+    for (int k = 0; k < parts; ++k) {
+        const hipStream_t sk = k ? ax.stream[k] : stream;
+        if (k) {
+            RSP_HIP(hipStreamWaitEvent(sk, ax.start, 0));
+            RSP_HIP(hipStreamWaitEvent(sk, ax.heavy[k - 1], 0));  // the heavy levels of the previous part are under way
+        }
+        first.run_window(X + col[k], ld, col[k + 1] - col[k], col[k], nrhs, sk, k + 1 < parts ? ax.heavy[k] : nullptr);
+        second.run_window(X + col[k], ld, col[k + 1] - col[k], col[k], nrhs, sk, nullptr);
+        if (k) RSP_HIP(hipEventRecord(ax.done[k], sk));
+    }
+    for (int k = 1; k < parts; ++k) RSP_HIP(hipStreamWaitEvent(stream, ax.done[k], 0));
 }
 
 void TriSolver::run_single(double *x, hipStream_t stream)
