@@ -112,9 +112,18 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     // (32 * bp columns accumulated in registers: fewer passes over the trailing part), the supernode as a whole updates
     // its ancestors when its last panel is done.
     const i64 bp = std::max<i64>(1, env_or("RSP_CHOL_BLOCK_PANELS", kCholBlockPanels));
+    // tiny leaf supernodes (chol_tiny_panels): factor and update fused, four panels to a wavefront
+    static const bool use_tiny = !(getenv("RSP_CHOL_TINY") && getenv("RSP_CHOL_TINY")[0] == '0');
+    std::vector<char> tiny(npanels_, 0);
+    if (use_tiny)
+        for (i64 k = 0; k < nsuper_; ++k) {
+            const i64 s = first_panel[k];
+            if (first_panel[k + 1] - s == 1 && c0[s + 1] - c0[s] <= 4 && (c0[s + 1] - c0[s]) + prow[s] <= 16) tiny[s] = 1;
+        }
     for (i64 k = 0; k < nsuper_; ++k) {
         const i64 sc = super[k], se = super[k + 1];
         for (i64 d = first_panel[k]; d < first_panel[k + 1]; ++d) {
+            if (tiny[d]) continue;
             const i64 *Rd = R(d);
             const i64 rd = prow[d];
             const i64 blk0 = first_panel[k] + (d - first_panel[k]) / bp * bp;      // first panel of d's block
@@ -142,9 +151,45 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             }
         }
     }
+    std::vector<dev::CholTiny> tiny_items;
+    std::vector<i64> tiny_tgt;
+    std::vector<i64> tiny_lv_ptr(nlevels_ + 1, 0);
+    std::vector<int32_t> tiny_incoming(nsuper_, -1);  // latest level at which a tiny panel updates supernode k
+    {
+        for (i64 s = 0; s < npanels_; ++s)
+            if (tiny[s]) tiny_lv_ptr[plev[s] + 1]++;
+        for (i64 l = 0; l < nlevels_; ++l) tiny_lv_ptr[l + 1] += tiny_lv_ptr[l];
+        tiny_items.resize((size_t)tiny_lv_ptr[nlevels_]);
+        std::vector<i64> fill(tiny_lv_ptr.begin(), tiny_lv_ptr.end() - 1);
+        std::vector<i64> order((size_t)tiny_lv_ptr[nlevels_]);
+        for (i64 s = 0; s < npanels_; ++s)
+            if (tiny[s]) order[fill[plev[s]]++] = s;
+        for (size_t k = 0; k < order.size(); ++k) {
+            const i64 s = order[k];
+            const i64 *Rs = R(s);
+            const i64 r = prow[s];
+            tiny_items[k] = dev::CholTiny{Lp_[c0[s]], (i64)tiny_tgt.size(), c0[s + 1] - c0[s], (int32_t)r, c0[s], 0};
+            for (i64 q = 0; q < r; ++q)
+                for (i64 qq = 0; qq <= q; ++qq) {
+                    const i64 rowi = Rs[q], col = Rs[qq];
+                    const i64 sp = panel_of[col], t = col - c0[sp], wsp = c0[sp + 1] - c0[sp];
+                    i64 pos;
+                    if (rowi < c0[sp + 1]) {
+                        pos = rowi - c0[sp];
+                    } else {
+                        const i64 *Rb = R(sp), *Re = Rb + prow[sp];
+                        const i64 *f = std::lower_bound(Rb, Re, rowi);
+                        if (f == Re || *f != rowi) return kBadInput;  // parent / cp do not describe this pattern
+                        pos = wsp + (f - Rb);
+                    }
+                    tiny_tgt.push_back(Lp_[col] + pos - t);
+                    tiny_incoming[super_of_panel[sp]] = std::max(tiny_incoming[super_of_panel[sp]], plev[s]);
+                }
+        }
+    }
     {   // plain stores inside a supernode are safe only if no other supernode still updates it while its panels are
         // being factored (true for fundamental supernodes: every other descendant hangs below the FIRST column)
-        std::vector<int32_t> incoming(nsuper_, -1);
+        std::vector<int32_t> incoming(tiny_incoming);
         for (const Pair &p : pairs)
             if (p.atomic) incoming[super_of_panel[p.s]] = std::max(incoming[super_of_panel[p.s]], p.level);
         for (Pair &p : pairs)
@@ -215,13 +260,14 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     for (i64 s = 0; s < npanels_; ++s) panel_rec[s] = dev::CholPanel{Lp_[c0[s]], c0[s + 1] - c0[s], prow[s]};
 
     // ---- per level: factor items, row-solve items of the tall panels, update items of the level's panels ------
-    levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0});
+    levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0, 0, 0});
     std::vector<int32_t> item_panel, item_block, multi, upd_pair, upd_q;
     for (i64 l = 0; l < nlevels_; ++l) {
         levels_[l].item_begin = (i64)item_panel.size();
         multi.clear();
         for (i64 k = lv_ptr[l]; k < lv_ptr[l + 1]; ++k) {
             const i64 s = lv_panels[k];
+            if (tiny[s]) continue;
             // panels with <= 64 rows below the diagonal block are finished by one wavefront (block 0); larger ones
             // get a diagonal-only item (block -1) now and their row blocks in a second launch
             item_panel.push_back((int32_t)s);
@@ -245,6 +291,8 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             }
         }
         levels_[l].upd_count = (i64)upd_pair.size() - levels_[l].upd_begin;
+        levels_[l].tiny_begin = tiny_lv_ptr[l];
+        levels_[l].tiny_count = tiny_lv_ptr[l + 1] - tiny_lv_ptr[l];
     }
     if (upd_pair.size() >= (size_t)INT32_MAX) return kBadInput;
     update_items_ = (i64)upd_pair.size();
@@ -261,6 +309,8 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     d_rel.upload(rel);
     d_upd_pair.upload(upd_pair);
     d_upd_q.upload(upd_q);
+    d_tiny.upload(tiny_items);
+    d_tiny_tgt.upload(tiny_tgt);
     d_item_panel.upload(item_panel);
     d_item_block.upload(item_block);
     d_status.resize(1);
@@ -299,7 +349,11 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
                            d_Adst.get(), annz_, d_Lx.get(), annz_, lnz_);
     const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get()};
     const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get()};
+    const dev::CholTinyArgs T{d_tiny.get(), d_tiny_tgt.get(), d_Lx.get(), d_status.get()};
     for (const Level &lv : levels_) {
+        if (lv.tiny_count)  // leaf supernodes of the level: factor + update in one kernel, 16 panels per workgroup
+            hipLaunchKernelGGL(dev::chol_tiny_panels, dim3((unsigned)((lv.tiny_count + 15) / 16), ny), dim3(256), 0, stream, T,
+                               lv.tiny_begin, lv.tiny_count, lnz_);
         if (lv.item_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4), ny), dim3(256), 0, stream, F,
                                lv.item_begin, lv.item_count, 0, lnz_);

@@ -61,11 +61,14 @@ class CholFactor {
     DeviceBuffer<int32_t> d_rel;              // per pair: position in the target panel of every updated row
     DeviceBuffer<int32_t> d_upd_pair, d_upd_q;  // update items: (pair, first row of the 16-row tile)
     DeviceBuffer<int32_t> d_item_panel, d_item_block;  // factor items: (panel, row block)
+    DeviceBuffer<dev::CholTiny> d_tiny;                // tiny leaf supernodes, by level
+    DeviceBuffer<i64> d_tiny_tgt;                      // their update targets (entry indices of L)
     DeviceBuffer<int32_t> d_status;  // [0] = smallest column with a non-positive pivot, or INT_MAX
     struct Level {
         i64 item_begin, item_count;  // factor work: whole small panels + diagonal blocks of large ones
         i64 trsm_begin, trsm_count;  // second launch: row blocks of the large panels
         i64 upd_begin, upd_count;    // third launch: rank updates from this level's panels
+        i64 tiny_begin, tiny_count;  // leaf supernodes handled whole by chol_tiny_panels
     };
     std::vector<Level> levels_;
     i64 update_items_ = 0;

@@ -250,6 +250,73 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     }
 }
 
+// ---- tiny panels: factor, row solve and update of a whole leaf supernode in a quarter of a wavefront ----------------
+// Half of the columns of a 2-D mesh factor are one-column leaves with two or three rows below them; a wavefront per
+// panel would idle 60 of its 64 lanes.  Panels with w <= 4 columns and w + r <= 16 rows that are a supernode of
+// their own run FOUR to a wavefront: a group of 16 lanes owns a panel, lane = row position (diagonal-block rows
+// first, then the rows below), the <= 4 columns live in registers and the pivot column travels by ds_bpermute.  The
+// same lanes then subtract the outer product of the rows below from the ancestors (hardware f64 atomics, as for every
+// update that leaves a supernode); the target entry of every (row, row') pair was tabulated by the host.
+struct CholTiny {     // 32 bytes
+    int64_t base;     // Lp[c0]
+    int64_t tgt_off;  // into tiny_tgt: entry index in Lx of (R[q], R[q']), q' <= q, at tgt_off + q (q + 1) / 2 + q'
+    int32_t w, r, c0, pad;
+};
+
+struct CholTinyArgs {
+    const CholTiny *items;
+    const int64_t *tgt;
+    double *Lx;
+    int32_t *status;
+};
+
+__global__ __launch_bounds__(256) void chol_tiny_panels(CholTinyArgs A, int64_t item_begin, int64_t nitems, int64_t lx_stride)
+{
+    double *Lx = A.Lx + (int64_t)blockIdx.y * lx_stride;
+    int32_t *status = A.status + blockIdx.y;
+    const int lane = threadIdx.x & 63, li = lane & 15, gbase = lane & 48;
+    const int64_t it = item_begin + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 16;
+    const bool have = it < item_begin + nitems;
+    CholTiny P = {0, 0, 0, 0, 0, 0};
+    if (have) P = A.items[it];
+    const int w = P.w, r = P.r, len0 = w + r, pos = li;
+    const bool row = have && pos < len0;
+    double d[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d[t] = (row && t < w && t <= pos) ? Lx[panel_entry(P.base, len0, pos, t)] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double dtt = __shfl(d[t], gbase + t, 64);  // every lane takes part in every exchange
+        double piv[4];
+        if (t < w) {
+            if (dtt <= 0.0 && li == 0) atomicMin(status, P.c0 + t);
+            const double l = sqrt(dtt);
+            if (row && pos >= t) d[t] = pos == t ? l : d[t] / l;  // L(k,i) = x_i / L(i,i), lib.rs:310
+        }
+#pragma unroll
+        for (int jj = t + 1; jj < 4; ++jj) piv[jj] = __shfl(d[t], gbase + jj, 64);
+#pragma unroll
+        for (int jj = t + 1; jj < 4; ++jj)
+            if (t < w && jj < w && row && pos >= jj) d[jj] -= d[t] * piv[jj];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (row && t < w && t <= pos) Lx[panel_entry(P.base, len0, pos, t)] = d[t];
+    // rank update from the rows below: lane = row q, loop over the rows q' <= q
+    const int q = pos - w;
+    const bool below = row && q >= 0;
+    const int64_t tbase = P.tgt_off + ((int64_t)q * (q + 1) >> 1);
+    for (int qq = 0; qq < 15; ++qq) {  // w >= 1, so r <= 15; uniform bound, lanes drop out by predicate
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double other = __shfl(d[t], (gbase + w + qq) & 63, 64);
+            if (t < w) v += d[t] * other;
+        }
+        if (below && qq <= q && qq < r) unsafeAtomicAdd(Lx + A.tgt[tbase + qq], -v);
+    }
+}
+
 // ---- batched cholsol solve phase: many small systems with one pattern --------------------------------------------
 // One workgroup per system; the vector lives in LDS for the whole of  x = P b, L x = b, L' x = b, b = P' x
 // (lib.rs:383-386).  Both sweeps are level-scheduled gathers (one thread per unknown of the level, a workgroup

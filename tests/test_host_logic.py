@@ -198,3 +198,20 @@ def test_block_programme_with_duplicate_entries():
         rep = rs.validate_program(D, kind)
         assert rep["bad_index"] == 0 and rep["order_violations"] == 0 and rep["unwritten"] == 0, rep
         assert rep["max_rel_error"] <= 1e-12, rep
+
+
+def test_batched_cholsol_rejects_bad_input_and_needs_a_gpu():
+    import torch
+    from rsparse_amd import synth
+    A = rs.Sprs.from_tuple(synth.circuit_spd(30, 6, 100))
+    vals = np.ascontiguousarray(A.x[None, :].copy())
+    B = np.ones((1, A.n))
+    # an empty batch is a no-op everywhere
+    assert rs.cholsol_batch(A, vals[:0], B[:0], 0).tolist() == []
+    # a non-square pattern is refused before anything touches a device
+    R = rs.Sprs(3, 2, [0, 1, 2], [0, 1], [1.0, 1.0])
+    with pytest.raises(rs.DeviceError):
+        rs.cholsol_batch(R, np.ones((1, 2)), np.ones((1, 2)), 0)
+    if not torch.cuda.is_available():  # no CPU fallback: the numeric path fails loudly without a GPU
+        with pytest.raises(rs.DeviceError):
+            rs.cholsol_batch(A, vals, B, 0)
