@@ -318,3 +318,67 @@ def test_cholsol_batch_empty_and_single():
     st, want = orc.cholsol(mats[0], B[0].copy(), 0)
     assert rel_inf(got[0], want) <= REL_X
     assert rs.cholsol_batch(mats[0], values[:0], got[:0], 0).tolist() == []
+
+
+# ---- BASELINE.json's full size (2-D Laplacian 1024^2): properties that need no reference run ---------------------------
+
+def test_full_size_properties():
+    """n = 1 048 576, nnz(L) = 47.5 M: the oracle would take minutes here, so the checks are size-independent ones:
+    the residual of A x = b, linearity of the solve, and columns of a wide block agreeing with one-column solves."""
+    import scipy.sparse as sp
+    A = synth.laplacian_2d(1024)
+    n = A[0]
+    Asp = sp.csc_matrix((A[4], A[3], A[2]), shape=(n, n))
+    S = rs.schol(A, 0)
+    F = rs.CholHandle(A, S)
+    assert F.info()["lnz"] == 47496134  # the pattern is an integer result: the same on every run and every machine
+    k = 192  # three 64-column chunks: the pair pipeline cuts it into unequal parts
+    B = np.asfortranarray((2.0 * synth.splitmix64(7, n * k) - 1.0).reshape(k, n).T)
+    X = B.copy(order="F")
+    F.solve(X)
+    for c in (0, 63, 64, 191):
+        r = Asp @ X[:, c] - B[:, c]
+        assert np.linalg.norm(r) / np.linalg.norm(B[:, c]) <= REL_RES
+    # one-column solves of the same right-hand sides
+    for c in (5, 130):
+        x1 = B[:, c].copy()
+        F.solve(x1)
+        assert rel_inf(X[:, c], x1) <= 1e-11
+    # linearity: solve(2 b1 - 3 b2) = 2 solve(b1) - 3 solve(b2)
+    mix = 2.0 * B[:, 1] - 3.0 * B[:, 2]
+    F.solve(mix)
+    assert rel_inf(mix, 2.0 * X[:, 1] - 3.0 * X[:, 2]) <= 1e-10
+    # the factor itself: L L' = P A P' on a probe vector, through the triangular products of scipy
+    L = F.factor()
+    Lsp = sp.csc_matrix((L.x, L.i.astype(np.int64), L.p), shape=(n, n))
+    v = 2.0 * synth.splitmix64(9, n) - 1.0
+    pinv = np.array(S.pinv)
+    pv = np.empty(n)
+    pv[pinv] = v  # (P v)[pinv[k]] = v[k]
+    lhs = Lsp @ (Lsp.T @ pv)
+    rhs = np.empty(n)
+    rhs[pinv] = Asp @ v
+    assert np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs) <= 1e-13
+
+
+def test_large_banded_lu_properties():
+    """BASELINE.json's unsymmetric configuration at a quarter of its size (n = 50 000; the host LU is the slow part):
+    residual of A x = b through lusol, and the handle's multi-column solve against its one-column solve."""
+    import scipy.sparse as sp
+    A = synth.banded_unsymmetric(50000)
+    n = A[0]
+    Asp = sp.csc_matrix((A[4], A[3], A[2]), shape=(n, n))
+    b = synth.splitmix64(5, n)
+    x = b.copy()
+    rs.lusol(A, x, 1, 1.0)
+    assert np.linalg.norm(Asp @ x - b) / np.linalg.norm(b) <= REL_RES
+    S = rs.sqr(A, 1)
+    N = rs.lu(A, S, 1.0)
+    B = np.asfortranarray(synth.splitmix64(6, n * 70).reshape(70, n).T)
+    X = B.copy(order="F")
+    N.solve(X)
+    for c in (0, 64, 69):
+        assert np.linalg.norm(Asp @ X[:, c] - B[:, c]) / np.linalg.norm(B[:, c]) <= REL_RES
+    x1 = B[:, 33].copy()
+    N.solve(x1)
+    assert rel_inf(X[:, 33], x1) <= 1e-11
