@@ -257,10 +257,15 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
         for (i64 k = 0; k < npairs; ++k) pair_by_level[fill[pairs[k].level]++] = (int32_t)k;
     }
     std::vector<dev::CholPanel> panel_rec(npanels_);
-    for (i64 s = 0; s < npanels_; ++s) panel_rec[s] = dev::CholPanel{Lp_[c0[s]], c0[s + 1] - c0[s], prow[s]};
+    ntall_ = 0;
+    for (i64 s = 0; s < npanels_; ++s) {
+        const int32_t dslot = prow[s] > 64 ? (int32_t)ntall_++ : -1;
+        panel_rec[s] = dev::CholPanel{Lp_[c0[s]], c0[s + 1] - c0[s], prow[s], dslot, 0};
+    }
+    static const i64 fuse_waves = env_or("RSP_CHOL_FUSE_WAVES", kCholFuseWaves);
 
     // ---- per level: factor items, row-solve items of the tall panels, update items of the level's panels ------
-    levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0, 0, 0});
+    levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0, 0, 0, false});
     std::vector<int32_t> item_panel, item_block, multi, upd_pair, upd_q;
     for (i64 l = 0; l < nlevels_; ++l) {
         levels_[l].item_begin = (i64)item_panel.size();
@@ -282,7 +287,30 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
                 item_block.push_back((int32_t)b);
             }
         levels_[l].trsm_count = (i64)item_panel.size() - levels_[l].trsm_begin;
+        // few row blocks: one fused launch (every row-block wavefront factors the diagonal block itself) and the
+        // parked diagonal blocks copied back by the update launch
+        levels_[l].fused = levels_[l].trsm_count > 0 && levels_[l].trsm_count <= fuse_waves;
+        if (levels_[l].fused) {
+            const i64 first = levels_[l].item_begin, count = levels_[l].item_count;
+            levels_[l].item_begin = (i64)item_panel.size();
+            for (i64 k = first; k < first + count; ++k)
+                if (item_block[k] == 0) {  // small panels as they were
+                    item_panel.push_back(item_panel[k]);
+                    item_block.push_back(0);
+                }
+            for (i64 k = levels_[l].trsm_begin; k < levels_[l].trsm_begin + levels_[l].trsm_count; ++k) {
+                item_panel.push_back(item_panel[k]);
+                item_block.push_back(item_block[k]);
+            }
+            levels_[l].item_count = (i64)item_panel.size() - levels_[l].item_begin;
+            levels_[l].trsm_count = 0;
+        }
         levels_[l].upd_begin = (i64)upd_pair.size();
+        if (levels_[l].fused)
+            for (int32_t s : multi) {
+                upd_pair.push_back(~s);
+                upd_q.push_back(0);
+            }
         for (i64 k = pair_lv_ptr[l]; k < pair_lv_ptr[l + 1]; ++k) {
             const i64 pk = pair_by_level[k];
             for (i64 q = pairs[pk].q0; q < prow[pairs[pk].d]; q += 16) {
@@ -347,8 +375,10 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
     if (annz_)
         hipLaunchKernelGGL(dev::chol_scatter_A, dim3((unsigned)((annz_ + 255) / 256), ny), dim3(256), 0, stream, d_Ax.get(),
                            d_Adst.get(), annz_, d_Lx.get(), annz_, lnz_);
-    const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get()};
-    const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get()};
+    d_dbuf.resize((size_t)std::max<i64>(1, ntall_) * 1024 * (size_t)nsys);
+    const i64 dstride = ntall_ * 1024;
+    const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get(), d_panels.get(), d_dbuf.get()};
+    const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get(), d_dbuf.get()};
     const dev::CholTinyArgs T{d_tiny.get(), d_tiny_tgt.get(), d_Lx.get(), d_status.get()};
     for (const Level &lv : levels_) {
         if (lv.tiny_count)  // leaf supernodes of the level: factor + update in one kernel, 16 panels per workgroup
@@ -356,13 +386,13 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
                                lv.tiny_begin, lv.tiny_count, lnz_);
         if (lv.item_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4), ny), dim3(256), 0, stream, F,
-                               lv.item_begin, lv.item_count, 0, lnz_);
+                               lv.item_begin, lv.item_count, lv.fused ? 2 : 0, lnz_, dstride);
         if (lv.trsm_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.trsm_count + 3) / 4), ny), dim3(256), 0, stream, F,
-                               lv.trsm_begin, lv.trsm_count, 1, lnz_);
+                               lv.trsm_begin, lv.trsm_count, 1, lnz_, dstride);
         if (lv.upd_count)  // the level's panels are final: subtract their outer products from their ancestors
             hipLaunchKernelGGL(dev::chol_rank_update, dim3((unsigned)((lv.upd_count + 3) / 4), ny), dim3(256), 0, stream, U,
-                               lv.upd_begin, lv.upd_count, lnz_);
+                               lv.upd_begin, lv.upd_count, lnz_, dstride);
     }
     RSP_HIP(hipEventRecord(ev1, stream));
     RSP_HIP(hipGetLastError());

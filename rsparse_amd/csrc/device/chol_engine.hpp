@@ -16,6 +16,7 @@
 namespace rsp {
 
 constexpr int kPanelWidth = 32;
+constexpr i64 kCholFuseWaves = 256;  // levels with at most this many row-block wavefronts factor and solve in one launch
 constexpr i64 kCholBlockPanels = 4;  // panels per block of the in-supernode updates (see chol_engine.hip)
 constexpr i64 kBatchMaxN = 16384;  // batched solve keeps the vector of a system in LDS (128 KiB)
 
@@ -69,9 +70,11 @@ class CholFactor {
         i64 trsm_begin, trsm_count;  // second launch: row blocks of the large panels
         i64 upd_begin, upd_count;    // third launch: rank updates from this level's panels
         i64 tiny_begin, tiny_count;  // leaf supernodes handled whole by chol_tiny_panels
+        bool fused;                  // factor and row solve in one launch (chol_panel_factor mode 2)
     };
     std::vector<Level> levels_;
-    i64 update_items_ = 0;
+    i64 update_items_ = 0, ntall_ = 0;
+    DeviceBuffer<double> d_dbuf;  // parked diagonal blocks of tall panels (fused levels)
     // batched solve phase: CSR index of L and the level sets of both sweeps
     i64 batch_ = 1;
     int32_t nlev_l_ = 0, nlev_t_ = 0;

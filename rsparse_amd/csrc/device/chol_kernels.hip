@@ -64,24 +64,35 @@ struct CholPair {        // 64 bytes
     int32_t pad[2];
 };
 
+struct CholPanel;
 struct CholUpdateArgs {
-    const int32_t *item_pair;  // work items of all levels: (pair, first q of the tile)
-    const int32_t *item_q;
+    const int32_t *item_pair;  // work items of all levels: (pair, first q of the tile); pair < 0: copy the parked
+    const int32_t *item_q;     //   diagonal block of panel ~pair from the side buffer into L (see chol_panel_factor)
     const CholPair *pairs;
     const int32_t *rel;
     double *Lx;
+    const CholPanel *panels;
+    const double *dbuf;
 };
+
+__device__ void chol_unpark_diagonal(const CholUpdateArgs &A, int panel, int lane);
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_t item_begin, int64_t nitems, int64_t lx_stride)
+__global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_t item_begin, int64_t nitems, int64_t lx_stride,
+                                                        int64_t dbuf_stride)
 {
     A.Lx += (int64_t)blockIdx.y * lx_stride;
+    A.dbuf += (int64_t)blockIdx.y * dbuf_stride;
     const int lane = threadIdx.x & 63;
     const int64_t it =
         item_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (it >= item_begin + nitems) return;
     const int pr = A.item_pair[it], qt = A.item_q[it];
+    if (pr < 0) {  // wave-uniform
+        chol_unpark_diagonal(A, ~pr, lane);
+        return;
+    }
     const CholPair P = A.pairs[pr];
     const int g = lane >> 4, j = lane & 15;
     const int ncols = __popc(P.mask);
@@ -152,9 +163,11 @@ __global__ __launch_bounds__(256) void chol_rank_update(CholUpdateArgs A, int64_
 }
 
 // ---- panel factorisation -------------------------------------------------------------------------------------
-struct CholPanel {   // 16 bytes
+struct CholPanel {   // 24 bytes
     int64_t base;    // Lp[c0]
     int32_t w, r;    // columns, rows below the diagonal block
+    int32_t dslot;   // tall panels (r > 64): slot of the factored diagonal block in the side buffer; else -1
+    int32_t pad;
 };
 
 struct CholFactorArgs {
@@ -164,7 +177,19 @@ struct CholFactorArgs {
     const int32_t *panel_c0;
     double *Lx;
     int32_t *status;  // smallest column whose pivot d <= 0 (lib.rs:325)
+    double *dbuf;     // side buffer: 1024 doubles per tall panel (mode 2)
 };
+
+__device__ void chol_unpark_diagonal(const CholUpdateArgs &A, int panel, int lane)
+{
+    const CholPanel P = A.panels[panel];
+    const int len0 = P.w + P.r;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = 64 * k + lane, rp = idx >> 5, t = idx & 31;
+        if (rp < P.w && t <= rp) A.Lx[panel_entry(P.base, len0, rp, t)] = A.dbuf[(int64_t)P.dslot * 1024 + rp * 32 + t];
+    }
+}
 
 // One wavefront per work item (panel, block).  Three kinds of item, chosen on the host so that no wavefront
 // reads a diagonal block while another one overwrites it:
@@ -173,10 +198,15 @@ struct CholFactorArgs {
 //   block == -1                : panel with more rows: factor the diagonal block and write it back, nothing else;
 //   trsm_only == 1 (next launch): load the already factored block and solve rows [64*block, 64*block + 64).
 // Row solve: lane = one row below the block,  x <- x * D^-T  (L(k,i) = x_i / L(i,i), lib.rs:310).
+// Mode 2 (levels with few panels, where a launch costs more than arithmetic): ONE launch; every row-block wavefront
+// of a tall panel factors the diagonal block itself, from the unfactored entries in L, and solves its rows.  Nobody
+// may overwrite those entries meanwhile, so wavefront 0 parks the factored block in a side buffer, and the level's
+// update launch copies it into L (chol_rank_update, item_pair < 0).
 __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64_t item_begin, int64_t nitems, int trsm_only,
-                                                         int64_t lx_stride)
+                                                         int64_t lx_stride, int64_t dbuf_stride)
 {
     A.Lx += (int64_t)blockIdx.y * lx_stride;
+    A.dbuf += (int64_t)blockIdx.y * dbuf_stride;
     A.status += blockIdx.y;  // one status word per system
     __shared__ double tiles[4][32][33];
     const int lane = threadIdx.x & 63;
@@ -195,7 +225,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     double x[32];
 #pragma unroll
     for (int t = 0; t < 32; ++t) x[t] = (solve && t < w) ? A.Lx[panel_entry(P.base, len0, pos, t)] : 0.0;
-    if (!trsm_only) {
+    if (trsm_only != 1) {
         // dense Cholesky of the diagonal block in registers: lane = row, d[t] = entry (lane, t); the pivot column
         // travels by readlane, so the 32 column steps are straight-line code without a single memory access
         double d[32];
@@ -205,7 +235,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
         for (int t = 0; t < 32; ++t) {
             if (t < w) {  // wave-uniform
                 const double dtt = readlane_f64(d[t], t);
-                if (dtt <= 0.0 && lane == 0) atomicMin(A.status, A.panel_c0[s] + t);
+                if (dtt <= 0.0 && lane == 0 && blk <= 0) atomicMin(A.status, A.panel_c0[s] + t);
                 const double l = sqrt(dtt);
                 d[t] = lane == t ? l : d[t] / l;  // L(k,i) = x_i / L(i,i), lib.rs:310
 #pragma unroll
@@ -213,9 +243,13 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
                     if (jj < w) d[jj] -= d[t] * readlane_f64(d[t], jj);  // above the diagonal (lane < jj) this collects values nothing reads
             }
         }
+        const bool parked = trsm_only == 2 && P.dslot >= 0;  // mode 2, tall panel: L keeps the unfactored block for now
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
-            if (lane < w && t <= lane) A.Lx[panel_entry(P.base, len0, lane, t)] = d[t];
+            if (lane < w && t <= lane) {
+                if (!parked) A.Lx[panel_entry(P.base, len0, lane, t)] = d[t];
+                else if (blk == 0) A.dbuf[(int64_t)P.dslot * 1024 + lane * 32 + t] = d[t];
+            }
             if (lane < 32) D[lane][t] = d[t];
         }
         if (blk < 0) return;
