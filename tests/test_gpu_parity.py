@@ -382,3 +382,17 @@ def test_large_banded_lu_properties():
     x1 = B[:, 33].copy()
     N.solve(x1)
     assert rel_inf(X[:, 33], x1) <= 1e-11
+
+
+def test_cholsol_batch_large_systems_take_the_ordinary_path():
+    """Systems too large for the LDS-resident batched solve (n > 16384) are factored and solved one by one."""
+    import scipy.sparse as sp
+    mats, values, B = _circuit_batch(17000, 2)
+    got = B.copy()
+    assert rs.cholsol_batch(mats[0], values, got, 0).tolist() == [0, 0]
+    for s, A in enumerate(mats):
+        Asp = sp.csc_matrix((A[4], A[3], A[2]), shape=(A[0], A[0]))
+        assert np.linalg.norm(Asp @ got[s] - B[s]) / np.linalg.norm(B[s]) <= REL_RES
+        one = B[s].copy()
+        rs.cholsol(A, one, 0)
+        assert rel_inf(got[s], one) <= 1e-11
