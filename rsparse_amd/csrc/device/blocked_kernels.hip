@@ -257,10 +257,50 @@ __device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t (
 // path, for levels with little work.  !PIPE: one stage of registers (half the footprint, twice the wavefronts per CU):
 // a stage's loads are only issued after the previous stage's MFMAs, and it is the OTHER wavefronts of the CU that
 // cover the wait -- the better trade on levels with thousands of blocks, where throughput is what counts.
+// ONE right-hand side: nothing but latency counts (a level is a handful of wavefronts waiting for a handful of doubles),
+// and registers are plentiful because only column 0 exists.  All stages of the wavefront (at most DEPTH per batch) are
+// fetched at once -- every id in one round trip, then every row and coefficient in one more -- instead of one
+// dependent gather per stage; only the first of the four column tiles is computed.
+template <int DEPTH>
+__device__ __forceinline__ void panel_gather_single(f64x4 (&acc)[4], const PanelCtx &c, int st_begin, int st_end)
+{
+    const bool mine = (c.lane & 15) == 0;  // lanes (g, 0) hold the B operand of column 0
+    for (int s0 = st_begin; s0 < st_end; s0 += DEPTH) {
+        int32_t id[DEPTH][4];
+        double a[DEPTH][4], b[DEPTH][4];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int st = min(s0 + d, st_end - 1);  // clamped: loads stay unconditional
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                id[d][q] = c.sidx[st * 16 + 4 * q + c.g];
+                a[d][q] = -c.cf[(int64_t)(st * 16 + 4 * q) * 16 + c.lane];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[d][q] = mine ? row_ptr(id[d][q], c.X, c.ldx, c.S, c.lds)[0] : 0.0;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (s0 + d < st_end) {  // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][q], b[d][q], acc[0], 0, 0, 0);
+            }
+    }
+}
+
 template <bool FAST, bool PIPE>
 __device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
+    if (!FAST && c.nrhs == 1) {  // wave-uniform
+        panel_ids_from(P, R, c, lead);
+        panel_load_rows<false>(acc, P.init, c);
+        load_panel_tinv(P, h, c);
+        panel_gather_single<PIPE ? 8 : 2>(acc, c, st_begin, st_end);
+        return;
+    }
     const int last = st_end - 1;
     const bool any = st_begin < st_end;  // wave-uniform; a block may have no sources at all
     int32_t idA[4];

@@ -235,6 +235,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
     const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && lds % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Sw % 16) == 0;
     static const i64 cluster_cpw = env_or("RSP_CLUSTER_CPW", 2);
     static const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
+    static const i64 lean_wgs_single = env_or("RSP_LEAN_WGS_SINGLE", kLeanLaunchWorkgroupsSingle);  // one right-hand side
     static const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);  // tests force the lean launch with 1
     // workgroups of the whole sweep (a proxy for its work), to find the point where the heavy part is over
     i64 total = 0, done = 0;
@@ -281,7 +282,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             L.wg2 = (int)((i64)lv.ntasks[3] * nchunks);
             const unsigned wgs = (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
             // few workgroups: latency counts, pipelined variant; many: the lean variant at twice the occupancy
-            const bool pipe = wgs < (unsigned)lean_wgs;
+            const bool pipe = wgs < (unsigned)(nrhs == 1 ? lean_wgs_single : lean_wgs);
             auto kernel = fast ? (pipe ? dev::solve_level<true, true> : dev::solve_level<true, false>)
                                : (pipe ? dev::solve_level<false, true> : dev::solve_level<false, false>);
             hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, nchunks);
