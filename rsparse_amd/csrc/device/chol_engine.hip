@@ -1,6 +1,7 @@
 // CholFactor: host-side construction of the panel/update programme, GPU numeric factorisation, and the
 // cholsol solve phase (P, lsolve, ltsolve, P') on the device.
 #include <algorithm>
+#include <cstring>
 #include <climits>
 
 #include "chol_engine.hpp"
@@ -9,6 +10,11 @@ namespace rsp {
 
 int CholFactor::analyze(const CscView &A, const Symbolic &S)
 {
+    double tmark = now_s();
+    auto lap = [&](const char *what) {
+        if (getenv("RSP_TIMING")) fprintf(stderr, "chol analyze: %s %.2fs\n", what, now_s() - tmark);
+        tmark = now_s();
+    };
     n_ = A.n;
     annz_ = A.nnz();
     has_pinv_ = S.has_pinv;
@@ -62,6 +68,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
         }
     }
 
+    lap("pattern of L and scatter map");
     // ---- panels: fundamental supernodes cut to kPanelWidth columns ------------------------------
     const std::vector<i64> super = fundamental_supernodes(S.parent, S.cp);
     nsuper_ = (i64)super.size() - 1;
@@ -114,6 +121,9 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     const i64 bp = std::max<i64>(1, env_or("RSP_CHOL_BLOCK_PANELS", kCholBlockPanels));
     // tiny leaf supernodes (chol_tiny_panels): factor and update fused, four panels to a wavefront
     static const bool use_tiny = !(getenv("RSP_CHOL_TINY") && getenv("RSP_CHOL_TINY")[0] == '0');
+    // target-owned updates (chol_tile_update): no atomics, bit-reproducible factor
+    grouped_ = env_or("RSP_CHOL_GROUPED", kCholGrouped) != 0;
+    const bool grouped = grouped_;
     std::vector<char> tiny(npanels_, 0);
     if (use_tiny)
         for (i64 k = 0; k < nsuper_; ++k) {
@@ -123,7 +133,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     for (i64 k = 0; k < nsuper_; ++k) {
         const i64 sc = super[k], se = super[k + 1];
         for (i64 d = first_panel[k]; d < first_panel[k + 1]; ++d) {
-            if (tiny[d]) continue;
+            if (tiny[d] && !grouped) continue;  // the tiny kernel applies its own updates, except in target-owned mode
             const i64 *Rd = R(d);
             const i64 rd = prow[d];
             const i64 blk0 = first_panel[k] + (d - first_panel[k]) / bp * bp;      // first panel of d's block
@@ -151,6 +161,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             }
         }
     }
+    lap("panels, levels, pairs");
     std::vector<dev::CholTiny> tiny_items;
     std::vector<i64> tiny_tgt;
     std::vector<i64> tiny_lv_ptr(nlevels_ + 1, 0);
@@ -169,7 +180,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             const i64 *Rs = R(s);
             const i64 r = prow[s];
             tiny_items[k] = dev::CholTiny{Lp_[c0[s]], (i64)tiny_tgt.size(), c0[s + 1] - c0[s], (int32_t)r, c0[s], 0};
-            for (i64 q = 0; q < r; ++q)
+            for (i64 q = 0; q < (grouped ? 0 : r); ++q)
                 for (i64 qq = 0; qq <= q; ++qq) {
                     const i64 rowi = Rs[q], col = Rs[qq];
                     const i64 sp = panel_of[col], t = col - c0[sp], wsp = c0[sp + 1] - c0[sp];
@@ -229,8 +240,74 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             }
         }
     }
-    std::vector<dev::CholPair> pair_rec(npairs);
-    for (i64 k = 0; k < npairs; ++k) {
+    lap("tiny tables, row positions");
+    // ---- target-owned mode: contributions regrouped by (level, target panel, 16-row tile) -----------------------------
+    std::vector<dev::CholSub> subs;
+    std::vector<dev::CholGroup> groups;
+    std::vector<int32_t> group_level;
+    if (grouped) {
+        struct Key { int32_t level, s, r16, pair, qa; };
+        std::vector<Key> gen;  // in generation order: pairs ascending, rows ascending
+        for (i64 k = 0; k < npairs; ++k) {
+            const Pair &p = pairs[k];
+            const int32_t *rp = rel.data() + rel_off[k];
+            const i64 cnt = prow[p.d] - p.q0;
+            for (i64 e = 0; e < cnt;) {
+                const int32_t tile = rp[e] >> 4;
+                gen.push_back(Key{p.level, p.s, tile, (int32_t)k, (int32_t)(p.q0 + e)});
+                while (e < cnt && (rp[e] >> 4) == tile) ++e;
+            }
+        }
+        if (gen.size() >= (size_t)UINT32_MAX) return kBadInput;
+        // order: level, target panel, tile, then generation order (which fixes the order of every sum).  Bucket by
+        // level first, then sort (panel, tile, ordinal) triples packed in two words inside each bucket.
+        std::vector<i64> lv_fill(nlevels_ + 1, 0);
+        for (const Key &key : gen) lv_fill[key.level + 1]++;
+        for (i64 l = 0; l < nlevels_; ++l) lv_fill[l + 1] += lv_fill[l];
+        std::vector<std::pair<uint64_t, uint32_t>> order(gen.size());
+        {
+            std::vector<i64> at(lv_fill.begin(), lv_fill.end() - 1);
+            for (size_t x = 0; x < gen.size(); ++x)
+                order[at[gen[x].level]++] = {((uint64_t)(uint32_t)gen[x].s << 32) | (uint32_t)gen[x].r16, (uint32_t)x};
+        }
+        for (i64 l = 0; l < nlevels_; ++l) std::sort(order.begin() + lv_fill[l], order.begin() + lv_fill[l + 1]);
+        std::vector<Key> keys(gen.size());
+        for (size_t x = 0; x < gen.size(); ++x) keys[x] = gen[order[x].second];
+        subs.resize(keys.size());
+        for (size_t x = 0; x < keys.size(); ++x) {
+            const Key &key = keys[x];
+            const Pair &p = pairs[key.pair];
+            const i64 sc = super[p.sup];
+            dev::CholSub &u = subs[x];
+            u.src_base = Lp_[sc];
+            u.len_d = (int32_t)(Lp_[sc + 1] - Lp_[sc]);
+            u.rs = prow[p.d];
+            u.q0 = p.q0;
+            u.mask = p.mask;
+            u.t_begin = p.t_begin;
+            u.t_end = p.t_end;
+            u.qa = key.qa;
+            u.pad = 0;
+            u.pad2[0] = u.pad2[1] = 0;
+            uint8_t map[16];
+            std::fill(map, map + 16, (uint8_t)0xff);
+            const int32_t *rp = rel.data() + rel_off[key.pair];
+            for (i64 q = key.qa; q < prow[p.d] && (rp[q - p.q0] >> 4) == key.r16; ++q) {
+                if (q - key.qa > 254) return kBadInput;  // cannot happen: at most 16 rows share a tile
+                map[rp[q - p.q0] & 15] = (uint8_t)(q - key.qa);
+            }
+            std::memcpy(u.rowmap, map, 16);
+            const bool fresh = x == 0 || keys[x - 1].level != key.level || keys[x - 1].s != key.s || keys[x - 1].r16 != key.r16;
+            if (fresh) {
+                groups.push_back(dev::CholGroup{Lp_[c0[p.s]], (i64)x, (c0[p.s + 1] - c0[p.s]) + prow[p.s], c0[p.s + 1] - c0[p.s], key.r16, 0});
+                group_level.push_back(key.level);
+            }
+            groups.back().sub_count++;
+        }
+    }
+    lap("target tiles");
+    std::vector<dev::CholPair> pair_rec(grouped ? 0 : npairs);  // source-owned mode only
+    for (i64 k = 0; k < (grouped ? 0 : npairs); ++k) {
         const Pair &p = pairs[k];
         dev::CholPair &r = pair_rec[k];
         const i64 sc = super[p.sup];
@@ -267,6 +344,8 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     // ---- per level: factor items, row-solve items of the tall panels, update items of the level's panels ------
     levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0, 0, 0, false});
     std::vector<int32_t> item_panel, item_block, multi, upd_pair, upd_q;
+    std::vector<dev::CholGroup> final_groups;
+    size_t next_group = 0;
     for (i64 l = 0; l < nlevels_; ++l) {
         levels_[l].item_begin = (i64)item_panel.size();
         multi.clear();
@@ -311,7 +390,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
                 upd_pair.push_back(~s);
                 upd_q.push_back(0);
             }
-        for (i64 k = pair_lv_ptr[l]; k < pair_lv_ptr[l + 1]; ++k) {
+        for (i64 k = pair_lv_ptr[l]; k < (grouped ? pair_lv_ptr[l] : pair_lv_ptr[l + 1]); ++k) {
             const i64 pk = pair_by_level[k];
             for (i64 q = pairs[pk].q0; q < prow[pairs[pk].d]; q += 16) {
                 upd_pair.push_back((int32_t)pk);
@@ -319,12 +398,20 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             }
         }
         levels_[l].upd_count = (i64)upd_pair.size() - levels_[l].upd_begin;
+        if (grouped) {  // the level's launch of chol_tile_update: parked diagonal blocks first, then its target tiles
+            levels_[l].upd_begin = (i64)final_groups.size();
+            if (levels_[l].fused)
+                for (int32_t s : multi) final_groups.push_back(dev::CholGroup{0, 0, 0, 0, -1, s});
+            for (; next_group < groups.size() && group_level[next_group] == l; ++next_group) final_groups.push_back(groups[next_group]);
+            levels_[l].upd_count = (i64)final_groups.size() - levels_[l].upd_begin;
+        }
         levels_[l].tiny_begin = tiny_lv_ptr[l];
         levels_[l].tiny_count = tiny_lv_ptr[l + 1] - tiny_lv_ptr[l];
     }
     if (upd_pair.size() >= (size_t)INT32_MAX) return kBadInput;
     update_items_ = (i64)upd_pair.size();
 
+    lap("records and work items");
     // ---- uploads ----------------------------------------------------------------------------------
     d_Lp.upload(Lp_);
     d_Lx.resize((size_t)lnz_);
@@ -334,14 +421,17 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     d_panel_c0.upload(c0);
     d_panels.upload(panel_rec);
     d_pairs.upload(pair_rec);
-    d_rel.upload(rel);
+    if (!grouped) d_rel.upload(rel);
     d_upd_pair.upload(upd_pair);
     d_upd_q.upload(upd_q);
     d_tiny.upload(tiny_items);
+    d_subs.upload(subs);
+    d_groups.upload(final_groups);
     d_tiny_tgt.upload(tiny_tgt);
     d_item_panel.upload(item_panel);
     d_item_block.upload(item_block);
     d_status.resize(1);
+    lap("uploads");
     return kOk;
 }
 
@@ -380,17 +470,21 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
     const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get(), d_panels.get(), d_dbuf.get()};
     const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get(), d_dbuf.get()};
     const dev::CholTinyArgs T{d_tiny.get(), d_tiny_tgt.get(), d_Lx.get(), d_status.get()};
+    const dev::CholTileArgs G{d_groups.get(), d_subs.get(), d_Lx.get(), d_panels.get(), d_dbuf.get()};
     for (const Level &lv : levels_) {
         if (lv.tiny_count)  // leaf supernodes of the level: factor + update in one kernel, 16 panels per workgroup
             hipLaunchKernelGGL(dev::chol_tiny_panels, dim3((unsigned)((lv.tiny_count + 15) / 16), ny), dim3(256), 0, stream, T,
-                               lv.tiny_begin, lv.tiny_count, lnz_);
+                               lv.tiny_begin, lv.tiny_count, lnz_, grouped_ ? 0 : 1);
         if (lv.item_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.item_count + 3) / 4), ny), dim3(256), 0, stream, F,
                                lv.item_begin, lv.item_count, lv.fused ? 2 : 0, lnz_, dstride);
         if (lv.trsm_count)
             hipLaunchKernelGGL(dev::chol_panel_factor, dim3((unsigned)((lv.trsm_count + 3) / 4), ny), dim3(256), 0, stream, F,
                                lv.trsm_begin, lv.trsm_count, 1, lnz_, dstride);
-        if (lv.upd_count)  // the level's panels are final: subtract their outer products from their ancestors
+        if (lv.upd_count && grouped_)  // target-owned tiles: plain stores, fixed order
+            hipLaunchKernelGGL(dev::chol_tile_update, dim3((unsigned)((lv.upd_count + 3) / 4), ny), dim3(256), 0, stream, G,
+                               lv.upd_begin, lv.upd_count, lnz_, dstride);
+        else if (lv.upd_count)  // the level's panels are final: subtract their outer products from their ancestors
             hipLaunchKernelGGL(dev::chol_rank_update, dim3((unsigned)((lv.upd_count + 3) / 4), ny), dim3(256), 0, stream, U,
                                lv.upd_begin, lv.upd_count, lnz_, dstride);
     }

@@ -284,6 +284,105 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     }
 }
 
+// ---- rank update, target-owned (atomics-free) --------------------------------------------------------------------
+// The same contributions as chol_rank_update, regrouped by what they WRITE: a 16-row x 32-column tile of a target
+// panel is owned, at every level, by one wavefront, which walks the (host-ordered) list of source ranges of that level
+// that touch the tile, accumulates them in TARGET coordinates -- A operand: column i of the panel <-> the
+// popcount(mask below i)-th column row of the source; B operand: row j of the tile <-> the source row the host's
+// 16-entry map names, or none -- and subtracts the tile from L once, with plain loads and stores.  No two wavefronts
+// of a launch write the same entry and the order of every sum is fixed by the host: the factor is bit-reproducible.
+struct CholSub {        // 64 bytes: one source range's contribution to one target tile
+    int64_t src_base;   // Lp[first column of the source supernode]
+    int32_t len_d, rs;  // its len0; rows of the q space
+    int32_t q0;         // first row of the q space that is a column of the target panel
+    uint32_t mask;      // bit i: column c0_s + i of the target panel is a row of the source
+    int32_t t_begin, t_end;
+    int32_t qa;         // first source row that falls into the tile
+    int32_t pad;
+    uint32_t rowmap[4]; // byte j: source row of tile row j, relative to qa, or 0xff
+    int32_t pad2[2];
+};
+
+struct CholGroup {      // 32 bytes: one target tile at one level
+    int64_t tgt_base;   // Lp[c0_s]
+    int64_t sub_begin;
+    int32_t len_s, w_s;
+    int32_t r16;        // rows 16 r16 .. 16 r16 + 15 of the panel; -1: copy the parked diagonal block of panel sub_count
+    int32_t sub_count;
+};
+
+struct CholTileArgs {
+    const CholGroup *groups;
+    const CholSub *subs;
+    double *Lx;
+    const CholPanel *panels;
+    const double *dbuf;
+};
+
+__global__ __launch_bounds__(256) void chol_tile_update(CholTileArgs A, int64_t group_begin, int64_t ngroups, int64_t lx_stride,
+                                                        int64_t dbuf_stride)
+{
+    A.Lx += (int64_t)blockIdx.y * lx_stride;
+    A.dbuf += (int64_t)blockIdx.y * dbuf_stride;
+    const int lane = threadIdx.x & 63;
+    const int64_t it =
+        group_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (it >= group_begin + ngroups) return;
+    const CholGroup G = A.groups[it];
+    if (G.r16 < 0) {  // wave-uniform
+        CholUpdateArgs U{nullptr, nullptr, nullptr, nullptr, A.Lx, A.panels, A.dbuf};
+        chol_unpark_diagonal(U, G.sub_count, lane);
+        return;
+    }
+    const int g = lane >> 4, j = lane & 15;
+    const uint32_t below0 = (1u << j) - 1u, below1 = (1u << (16 + j)) - 1u;
+    f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+    CholSub next = A.subs[G.sub_begin];  // wave-uniform (scalar loads); a group has at least one source range
+    for (int k = 0; k < G.sub_count; ++k) {
+        const CholSub S = next;
+        next = A.subs[G.sub_begin + min(k + 1, G.sub_count - 1)];  // in flight while this range is gathered and multiplied
+        const int rowbase = S.len_d - S.rs;
+        const uint32_t word = j < 8 ? (j < 4 ? S.rowmap[0] : S.rowmap[1]) : (j < 12 ? S.rowmap[2] : S.rowmap[3]);
+        const int rm = (int)((word >> (8 * (j & 3))) & 0xffu);
+        const bool row_ok = rm != 0xff;
+        const bool col0_ok = (S.mask >> j) & 1u, col1_ok = (S.mask >> (16 + j)) & 1u;
+        const bool two = (S.mask >> 16) != 0u;
+        const int pos_r = rowbase + S.qa + rm;
+        const int pos_c0 = rowbase + S.q0 + __popc(S.mask & below0), pos_c1 = rowbase + S.q0 + __popc(S.mask & below1);
+        for (int t0 = S.t_begin; t0 < S.t_end; t0 += 32) {  // wave-uniform
+            const int wc = min(32, S.t_end - t0);
+            const int ksteps = (wc + 3) >> 2;
+            double a0[8], a1[8], b[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                a0[kk] = a1[kk] = b[kk] = 0.0;
+                if (kk < ksteps) {
+                    const int u = 4 * kk + g;
+                    const bool col = u < wc;
+                    if (col && row_ok) b[kk] = A.Lx[panel_entry(S.src_base, S.len_d, pos_r, t0 + u)];
+                    if (col && col0_ok) a0[kk] = A.Lx[panel_entry(S.src_base, S.len_d, pos_c0, t0 + u)];
+                    if (two && col && col1_ok) a1[kk] = A.Lx[panel_entry(S.src_base, S.len_d, pos_c1, t0 + u)];
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (kk < ksteps) {
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b[kk], c0, 0, 0, 0);
+                    if (two) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b[kk], c1, 0, 0, 0);
+                }
+        }
+    }
+    // C layout: lane (g, j), register s  <->  panel column 4s + g (+ 16), tile row j
+    const int pos = 16 * G.r16 + j;
+    if (pos >= G.len_s) return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i0 = 4 * s + g, i1 = i0 + 16;
+        if (i0 < G.w_s && i0 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i0)] -= c0[s];
+        if (i1 < G.w_s && i1 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i1)] -= c1[s];
+    }
+}
+
 // ---- tiny panels: factor, row solve and update of a whole leaf supernode in a quarter of a wavefront ----------------
 // Half of the columns of a 2-D mesh factor are one-column leaves with two or three rows below them; a wavefront per
 // panel would idle 60 of its 64 lanes.  Panels with w <= 4 columns and w + r <= 16 rows that are a supernode of
@@ -304,7 +403,7 @@ struct CholTinyArgs {
     int32_t *status;
 };
 
-__global__ __launch_bounds__(256) void chol_tiny_panels(CholTinyArgs A, int64_t item_begin, int64_t nitems, int64_t lx_stride)
+__global__ __launch_bounds__(256) void chol_tiny_panels(CholTinyArgs A, int64_t item_begin, int64_t nitems, int64_t lx_stride, int update)
 {
     double *Lx = A.Lx + (int64_t)blockIdx.y * lx_stride;
     int32_t *status = A.status + blockIdx.y;
@@ -336,6 +435,7 @@ __global__ __launch_bounds__(256) void chol_tiny_panels(CholTinyArgs A, int64_t 
 #pragma unroll
     for (int t = 0; t < 4; ++t)
         if (row && t < w && t <= pos) Lx[panel_entry(P.base, len0, pos, t)] = d[t];
+    if (!update) return;  // wave-uniform: the target-owned update kernel does it
     // rank update from the rows below: lane = row q, loop over the rows q' <= q
     const int q = pos - w;
     const bool below = row && q >= 0;

@@ -396,3 +396,16 @@ def test_cholsol_batch_large_systems_take_the_ordinary_path():
         one = B[s].copy()
         rs.cholsol(A, one, 0)
         assert rel_inf(got[s], one) <= 1e-11
+
+
+def test_chol_is_bit_reproducible():
+    """The numeric factorisation owns every target tile with one wavefront and sums in a host-fixed order (no atomics):
+    two factorisations of the same matrix give the same bits, as the sequential reference does."""
+    for A in (synth.laplacian_2d(160), synth.laplacian_3d(20), synth.circuit_spd(3000)):
+        S = rs.schol(A, 0)
+        L1 = rs.CholHandle(A, S).factor()
+        L2 = rs.CholHandle(A, S).factor()
+        assert np.array_equal(L1.x, L2.x)
+        st, Lo = orc.chol(A, orc.schol(A, 0))
+        assert st == orc.OK and L1.i.astype(np.int64).tolist() == Lo[3].tolist()
+        assert rel_inf(L1.x, Lo[4]) <= 1e-11
