@@ -589,20 +589,29 @@ void CholFactor::solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool per
         solve_pair_device(*lower_, *upper_, dB, ld, nrhs, stream);  // lsolve, ltsolve (lib.rs:384-385)
         return;
     }
+    if (vector && !perm) {  // a vector is its own n x 1 row-major block
+        solve_pair_device(*lower_, *upper_, dB, 1, 1, stream);
+        return;
+    }
     work_.resize((size_t)n_ * (size_t)((layout == 1 && !vector) ? ld : nrhs));
     double *W = work_.get();
     const dim3 tgrid((unsigned)((n_ + 31) / 32), (unsigned)((nrhs + 31) / 32)), tblock(256);
     const dim3 pgrid((unsigned)((n_ + 3) / 4)), pblock(256);
     // x = P b : x[pinv[k]] = b[k]  (ipvec, lib.rs:383)
-    if (layout == 0 || vector)
-        hipLaunchKernelGGL(dev::colmajor_to_rowmajor, tgrid, tblock, 0, stream, dB, vector ? n_ : ld, W, nrhs, n_, (int)nrhs, pinv, 1);
+    const dim3 vgrid((unsigned)((n_ + 255) / 256));
+    if (vector)
+        hipLaunchKernelGGL(dev::permute_vector, vgrid, dim3(256), 0, stream, dB, W, n_, pinv, 1);
+    else if (layout == 0)
+        hipLaunchKernelGGL(dev::colmajor_to_rowmajor, tgrid, tblock, 0, stream, dB, ld, W, nrhs, n_, (int)nrhs, pinv, 1);
     else
         hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, dB, W, ld, n_, (int)nrhs, pinv, 1);
     const i64 ldw = (layout == 0 || vector) ? nrhs : ld;
     solve_pair_device(*lower_, *upper_, W, ldw, nrhs, stream);  // x = L \ x, x = L' \ x  (lib.rs:384-385)
     // b = P' x : b[k] = x[pinv[k]]  (pvec, lib.rs:386)
-    if (layout == 0 || vector)
-        hipLaunchKernelGGL(dev::rowmajor_to_colmajor, tgrid, tblock, 0, stream, W, nrhs, dB, vector ? n_ : ld, n_, (int)nrhs, pinv, 0);
+    if (vector)
+        hipLaunchKernelGGL(dev::permute_vector, vgrid, dim3(256), 0, stream, W, dB, n_, pinv, 0);
+    else if (layout == 0)
+        hipLaunchKernelGGL(dev::rowmajor_to_colmajor, tgrid, tblock, 0, stream, W, nrhs, dB, ld, n_, (int)nrhs, pinv, 0);
     else
         hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, W, dB, ld, n_, (int)nrhs, pinv, 0);
     RSP_HIP(hipGetLastError());

@@ -175,6 +175,17 @@ __global__ __launch_bounds__(256) void permute_rows(const double *__restrict__ i
     for (int r = threadIdx.x & 63; r < k; r += 64) out[dst * ld + r] = in[src * ld + r];
 }
 
+// one vector (ipvec / pvec, lib.rs:2151 / 2244): out[perm[i]] = in[i] or out[i] = in[perm[i]]; perm may be null
+__global__ __launch_bounds__(256) void permute_vector(const double *__restrict__ in, double *__restrict__ out, int64_t n,
+                                                      const int64_t *__restrict__ perm, int scatter)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t p = perm ? perm[i] : i;
+    if (scatter) out[p] = in[i];
+    else out[i] = in[p];
+}
+
 }  // namespace dev
 }  // namespace rsp
 
