@@ -245,6 +245,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     std::vector<dev::CholSub> subs;
     std::vector<dev::CholGroup> groups;
     std::vector<int32_t> group_level;
+    std::vector<char> group_long;  // some source range of the group has more than 4 columns
     if (grouped) {
         struct Key { int32_t level, s, r16, pair, qa; };
         std::vector<Key> gen;  // in generation order: pairs ascending, rows ascending
@@ -301,8 +302,10 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             if (fresh) {
                 groups.push_back(dev::CholGroup{Lp_[c0[p.s]], (i64)x, (c0[p.s + 1] - c0[p.s]) + prow[p.s], c0[p.s + 1] - c0[p.s], key.r16, 0});
                 group_level.push_back(key.level);
+                group_long.push_back(0);
             }
             groups.back().sub_count++;
+            if (p.t_end - p.t_begin > 4) group_long.back() = 1;
         }
     }
     lap("target tiles");
@@ -346,6 +349,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     std::vector<int32_t> item_panel, item_block, multi, upd_pair, upd_q;
     std::vector<dev::CholGroup> final_groups;
     size_t next_group = 0;
+    static const bool short_groups = env_or("RSP_CHOL_SHORT_GROUPS", 1) != 0;
     for (i64 l = 0; l < nlevels_; ++l) {
         levels_[l].item_begin = (i64)item_panel.size();
         multi.clear();
@@ -402,7 +406,10 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             levels_[l].upd_begin = (i64)final_groups.size();
             if (levels_[l].fused)
                 for (int32_t s : multi) final_groups.push_back(dev::CholGroup{0, 0, 0, 0, -1, s});
-            for (; next_group < groups.size() && group_level[next_group] == l; ++next_group) final_groups.push_back(groups[next_group]);
+            for (; next_group < groups.size() && group_level[next_group] == l; ++next_group) {
+                final_groups.push_back(groups[next_group]);
+                if (!group_long[next_group] && short_groups) final_groups.back().w_s = -final_groups.back().w_s;  // fast path
+            }
             levels_[l].upd_count = (i64)final_groups.size() - levels_[l].upd_begin;
         }
         levels_[l].tiny_begin = tiny_lv_ptr[l];

@@ -306,7 +306,7 @@ struct CholSub {        // 64 bytes: one source range's contribution to one targ
 struct CholGroup {      // 32 bytes: one target tile at one level
     int64_t tgt_base;   // Lp[c0_s]
     int64_t sub_begin;
-    int32_t len_s, w_s;
+    int32_t len_s, w_s; // w_s < 0: -w_s columns, and every source range of the group has at most 4 columns (fast path)
     int32_t r16;        // rows 16 r16 .. 16 r16 + 15 of the panel; -1: copy the parked diagonal block of panel sub_count
     int32_t sub_count;
 };
@@ -337,6 +337,46 @@ __global__ __launch_bounds__(256) void chol_tile_update(CholTileArgs A, int64_t 
     const int g = lane >> 4, j = lane & 15;
     const uint32_t below0 = (1u << j) - 1u, below1 = (1u << (16 + j)) - 1u;
     f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+    if (G.w_s < 0) {
+        // every source range of this group has at most 4 columns (the tiles next to the leaves: several one-column
+        // contributions each): four ranges per round trip instead of one
+        const int w_s = -G.w_s;
+        for (int k0 = 0; k0 < G.sub_count; k0 += 4) {
+            double a0[4], a1[4], b[4];
+            bool two[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool have = k0 + u < G.sub_count;  // wave-uniform
+                const CholSub S = A.subs[G.sub_begin + min(k0 + u, G.sub_count - 1)];
+                const int rowbase = S.len_d - S.rs;
+                const uint32_t word = j < 8 ? (j < 4 ? S.rowmap[0] : S.rowmap[1]) : (j < 12 ? S.rowmap[2] : S.rowmap[3]);
+                const int rm = (int)((word >> (8 * (j & 3))) & 0xffu);
+                const bool col = have && S.t_begin + g < S.t_end;
+                two[u] = have && (S.mask >> 16) != 0u;
+                a0[u] = a1[u] = b[u] = 0.0;
+                if (col && rm != 0xff) b[u] = A.Lx[panel_entry(S.src_base, S.len_d, rowbase + S.qa + rm, S.t_begin + g)];
+                if (col && ((S.mask >> j) & 1u))
+                    a0[u] = A.Lx[panel_entry(S.src_base, S.len_d, rowbase + S.q0 + __popc(S.mask & below0), S.t_begin + g)];
+                if (col && ((S.mask >> (16 + j)) & 1u))
+                    a1[u] = A.Lx[panel_entry(S.src_base, S.len_d, rowbase + S.q0 + __popc(S.mask & below1), S.t_begin + g)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < G.sub_count) {
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u], c0, 0, 0, 0);
+                    if (two[u]) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u], c1, 0, 0, 0);
+                }
+        }
+        const int pos = 16 * G.r16 + j;
+        if (pos >= G.len_s) return;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i0 = 4 * s + g, i1 = i0 + 16;
+            if (i0 < w_s && i0 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i0)] -= c0[s];
+            if (i1 < w_s && i1 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i1)] -= c1[s];
+        }
+        return;
+    }
     CholSub next = A.subs[G.sub_begin];  // wave-uniform (scalar loads); a group has at least one source range
     for (int k = 0; k < G.sub_count; ++k) {
         const CholSub S = next;
