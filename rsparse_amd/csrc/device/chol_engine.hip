@@ -435,8 +435,11 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     d_subs.upload(subs);
     d_groups.upload(final_groups);
     d_tiny_tgt.upload(tiny_tgt);
-    d_item_panel.upload(item_panel);
-    d_item_block.upload(item_block);
+    {
+        std::vector<dev::CholFactorItem> items(item_panel.size());
+        for (size_t k = 0; k < items.size(); ++k) items[k] = dev::CholFactorItem{panel_rec[item_panel[k]], item_block[k], c0[item_panel[k]]};
+        d_items.upload(items);
+    }
     d_status.resize(1);
     lap("uploads");
     return kOk;
@@ -475,7 +478,7 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
     d_dbuf.resize((size_t)std::max<i64>(1, ntall_) * 1024 * (size_t)nsys);
     const i64 dstride = ntall_ * 1024;
     const dev::CholUpdateArgs U{d_upd_pair.get(), d_upd_q.get(), d_pairs.get(), d_rel.get(), d_Lx.get(), d_panels.get(), d_dbuf.get()};
-    const dev::CholFactorArgs F{d_item_panel.get(), d_item_block.get(), d_panels.get(), d_panel_c0.get(), d_Lx.get(), d_status.get(), d_dbuf.get()};
+    const dev::CholFactorArgs F{d_items.get(), d_Lx.get(), d_status.get(), d_dbuf.get()};
     const dev::CholTinyArgs T{d_tiny.get(), d_tiny_tgt.get(), d_Lx.get(), d_status.get()};
     const dev::CholTileArgs G{d_groups.get(), d_subs.get(), d_Lx.get(), d_panels.get(), d_dbuf.get()};
     for (const Level &lv : levels_) {

@@ -64,7 +64,7 @@ class CholFactor {
     DeviceBuffer<dev::CholPair> d_pairs;
     DeviceBuffer<int32_t> d_rel;              // per pair: position in the target panel of every updated row
     DeviceBuffer<int32_t> d_upd_pair, d_upd_q;  // update items: (pair, first row of the 16-row tile)
-    DeviceBuffer<int32_t> d_item_panel, d_item_block;  // factor items: (panel, row block)
+    DeviceBuffer<dev::CholFactorItem> d_items;         // factor items: (panel record, row block)
     DeviceBuffer<dev::CholTiny> d_tiny;                // tiny leaf supernodes, by level
     DeviceBuffer<i64> d_tiny_tgt;                      // their update targets (entry indices of L)
     DeviceBuffer<int32_t> d_status;  // [0] = smallest column with a non-positive pivot, or INT_MAX

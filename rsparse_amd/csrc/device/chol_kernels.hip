@@ -170,11 +170,14 @@ struct CholPanel {   // 24 bytes
     int32_t pad;
 };
 
+struct CholFactorItem {  // 32 bytes: the panel's record travels with the item (one round trip before the data)
+    CholPanel panel;
+    int32_t block;       // row block of 64, or -1: diagonal block only
+    int32_t c0;          // first column (for the status word)
+};
+
 struct CholFactorArgs {
-    const int32_t *item_panel;
-    const int32_t *item_block;
-    const CholPanel *panels;
-    const int32_t *panel_c0;
+    const CholFactorItem *items;
     double *Lx;
     int32_t *status;  // smallest column whose pivot d <= 0 (lib.rs:325)
     double *dbuf;     // side buffer: 1024 doubles per tall panel (mode 2)
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
     const int64_t it = item_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
     if (it >= item_begin + nitems) return;
     double(*D)[33] = tiles[wv];
-    const int s = A.item_panel[it], blk = A.item_block[it];
-    const CholPanel P = A.panels[s];
-    const int w = P.w, r = P.r, len0 = w + r;
+    const CholFactorItem I = A.items[it];
+    const CholPanel P = I.panel;
+    const int blk = I.block, w = P.w, r = P.r, len0 = w + r;
 
     // the diagonal block and (when this item solves rows) this lane's row: all loads of one round trip
     const int rr = blk * 64 + lane;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
         for (int t = 0; t < 32; ++t) {
             if (t < w) {  // wave-uniform
                 const double dtt = readlane_f64(d[t], t);
-                if (dtt <= 0.0 && lane == 0 && blk <= 0) atomicMin(A.status, A.panel_c0[s] + t);
+                if (dtt <= 0.0 && lane == 0 && blk <= 0) atomicMin(A.status, I.c0 + t);
                 const double l = sqrt(dtt);
                 d[t] = lane == t ? l : d[t] / l;  // L(k,i) = x_i / L(i,i), lib.rs:310
 #pragma unroll
