@@ -166,7 +166,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        # lsolve then ltsolve on the same block; the library pipelines the two column halves over two streams
+        # lsolve then ltsolve on the same block; the library pipelines column parts of the block over several streams
         rs.solve_pair_dev(lower, upper, X.data_ptr(), nrhs, nrhs, stream)
 
     # correctness of the timed path itself (rank 0, first column): L L' y = b against scipy's triangular solves

@@ -294,9 +294,9 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
 }
 
 // first.solve then second.solve on the same row-major block (lsolve + ltsolve of cholsol, lsolve + usolve of lusol).
-// Wide blocks are cut into two column halves that travel through both sweeps on two streams, the second half
-// starting when the heavy levels of the first half's first sweep are over: the long chains of nearly empty levels
-// at the top of the tree (latency-bound, the chip idles) then run beside the other half's heavy levels.
+// Wide blocks are cut into column parts (kPairParts) that travel through both sweeps on streams of their own, each part
+// starting when the heavy levels of the previous part's first sweep are over: the long chains of nearly empty levels
+// at the top of the tree (latency-bound, the chip idles) then run beside another part's heavy levels.
 void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i64 nrhs, hipStream_t stream)
 {
     if (nrhs <= 0 || first.n() == 0) return;
@@ -314,7 +314,7 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i
         hipEvent_t start = nullptr, heavy[kMaxParts] = {}, done[kMaxParts] = {};
     };
     static thread_local std::vector<Aux> per_device;
-    static const i64 want_parts = std::max<i64>(2, std::min<i64>(kMaxParts, env_or("RSP_PAIR_PARTS", 2)));
+    static const i64 want_parts = std::max<i64>(2, std::min<i64>(kMaxParts, env_or("RSP_PAIR_PARTS", kPairParts)));
     int device = 0;
     RSP_HIP(hipGetDevice(&device));
     if ((size_t)device >= per_device.size()) per_device.resize(device + 1);

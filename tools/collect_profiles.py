@@ -1,8 +1,11 @@
 """Condense rocprofv3 outputs under gpurun_out/ into the small, tracked summaries under profiles/.
 usage: collect_profiles.py <tag> <stats_dir> <bench.json of that run> [<fetch_dir> <write_dir>]
-The LAST bench step is the span from the 4th-to-last solve_clusters launch to the last one: a step solves two column
-halves (pair pipeline), each with one cluster launch in lsolve (its first) and one in ltsolve (its last)."""
-import csv, glob, json, sys, collections
+The LAST bench step is the span from the (2 x PARTS)-th-to-last solve_clusters launch to the last one: a step solves PARTS
+column parts (pair pipeline, engine.hpp kPairParts), each with one cluster launch in lsolve (its first) and one in ltsolve
+(its last)."""
+import csv, glob, json, os, sys, collections
+
+PARTS = int(os.environ.get("RSP_PAIR_PARTS", "2"))
 
 tag, stats_dir = sys.argv[1], sys.argv[2]
 bench = json.load(open(sys.argv[3]))
@@ -12,7 +15,7 @@ ours = lambda name: 'solve_level' in name or 'solve_clusters' in name
 def last_step(rows, key):
     rows = sorted(rows, key=key)
     idx = [i for i, r in enumerate(rows) if 'clusters' in r['Kernel_Name']]
-    return rows[idx[-4]:]
+    return rows[idx[-2 * PARTS]:]
 
 
 out = {"tag": tag, "config": bench["config"], "ms_per_step_under_profiler": bench["ms_per_step"],
