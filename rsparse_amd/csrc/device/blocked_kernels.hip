@@ -257,6 +257,84 @@ __device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t (
 // path, for levels with little work.  !PIPE: one stage of registers (half the footprint, twice the wavefronts per CU):
 // a stage's loads are only issued after the previous stage's MFMAs, and it is the OTHER wavefronts of the CU that
 // cover the wait -- the better trade on levels with thousands of blocks, where throughput is what counts.
+// Lean variant with HALF stages (PIPE == 2): the same 16 sources' worth of registers as the one-stage lean variant, but as
+// two half stages of 8 that alternate -- while one half is multiplied the other one is in flight, and the ids run two
+// halves ahead, so a wavefront never sits with nothing outstanding.
+struct HalfStage {
+    double a[2];
+    f64x2 lo[2], hi[2];
+};
+
+__device__ __forceinline__ void load_half_ids(int32_t (&id)[2], const PanelCtx &c, int hs)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) id[q] = c.sidx[hs * 8 + 4 * q + c.g];
+}
+
+template <bool FAST>
+__device__ __forceinline__ void load_half(HalfStage &R, const int32_t (&id)[2], const PanelCtx &c, int hs)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        R.a[q] = -c.cf[(int64_t)(hs * 8 + 4 * q) * 16 + c.lane];
+        const double *p = row_ptr(id[q], c.X, c.ldx, c.S, c.lds);
+        if (FAST) {
+            p += c.in ? c.cb : 0;
+            R.lo[q] = *reinterpret_cast<const f64x2 *>(p);
+            R.hi[q] = *reinterpret_cast<const f64x2 *>(p + 2);
+        } else {
+            p += c.cb;
+            R.lo[q].x = c.cb + 0 < c.nrhs ? p[0] : 0.0;
+            R.lo[q].y = c.cb + 1 < c.nrhs ? p[1] : 0.0;
+            R.hi[q].x = c.cb + 2 < c.nrhs ? p[2] : 0.0;
+            R.hi[q].y = c.cb + 3 < c.nrhs ? p[3] : 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void mfma_half(f64x4 (&acc)[4], const HalfStage &R)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].x, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].y, acc[3], 0, 0, 0);
+    }
+}
+
+// stages [st_begin, st_end) of 16 sources = half stages [2 st_begin, 2 st_end); the record holds the ids of the first two
+template <bool FAST>
+__device__ __forceinline__ void gather_halves(f64x4 (&acc)[4], const Prologue &R, const PanelCtx &c, int st_begin, int st_end)
+{
+    if (st_begin >= st_end) return;  // wave-uniform
+    const int h0 = 2 * st_begin, hend = 2 * st_end, hlast = hend - 1;
+    int32_t idA[2], idB[2], idA2[2], idB2[2];
+    HalfStage A, B;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        idA[q] = word_at(R.r0, 40 + 4 * q + c.g);
+        idB[q] = word_at(R.r0, 48 + 4 * q + c.g);
+    }
+    load_half_ids(idA2, c, min(h0 + 2, hlast));
+    load_half_ids(idB2, c, min(h0 + 3, hlast));
+    load_half<FAST>(A, idA, c, h0);
+    load_half<FAST>(B, idB, c, h0 + 1);
+    for (int hs = h0; hs < hend; hs += 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            idA[q] = idA2[q];
+            idB[q] = idB2[q];
+        }
+        load_half_ids(idA2, c, min(hs + 4, hlast));
+        load_half_ids(idB2, c, min(hs + 5, hlast));
+        mfma_half(acc, A);
+        load_half<FAST>(A, idA, c, min(hs + 2, hlast));
+        mfma_half(acc, B);
+        load_half<FAST>(B, idB, c, min(hs + 3, hlast));
+    }
+}
+
 // ONE right-hand side: nothing but latency counts (a level is a handful of wavefronts waiting for a handful of doubles),
 // and registers are plentiful because only column 0 exists.  All stages of the wavefront (at most DEPTH per batch) are
 // fetched at once -- every id in one round trip, then every row and coefficient in one more -- instead of one
@@ -290,7 +368,7 @@ __device__ __forceinline__ void panel_gather_single(f64x4 (&acc)[4], const Panel
     }
 }
 
-template <bool FAST, bool PIPE>
+template <bool FAST, int PIPE>
 __device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
@@ -298,7 +376,7 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const
         panel_ids_from(P, R, c, lead);
         panel_load_rows<false>(acc, P.init, c);
         load_panel_tinv(P, h, c);
-        panel_gather_single<PIPE ? 8 : 2>(acc, c, st_begin, st_end);
+        panel_gather_single<PIPE == 1 ? 8 : 2>(acc, c, st_begin, st_end);
         return;
     }
     const int last = st_end - 1;
@@ -309,7 +387,11 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const
     panel_ids_from(P, R, c, lead);
 #pragma unroll
     for (int q = 0; q < 4; ++q) idA[q] = word_at(R.r0, 40 + 4 * q + c.g);
-    if (PIPE) {
+    if (PIPE == 2) {
+        panel_load_rows<FAST>(acc, P.init, c);
+        gather_halves<FAST>(acc, R, c, st_begin, st_end);
+        load_panel_tinv(P, h, c);
+    } else if (PIPE == 1) {
         int32_t idB[4];
         Stage B;
 #pragma unroll
@@ -391,7 +473,7 @@ __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArr
     return c;
 }
 
-template <bool FAST, bool PIPE>
+template <bool FAST, int PIPE>
 __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const Prologue &R, const BlockArrays &B, double *X, int64_t ldx, double *S,
                                                int64_t lds, int cw, int nrhs, int lane)
 {
@@ -423,7 +505,7 @@ struct LevelDesc {
 };
 
 // class 0: the blocks of a task run in order.  t = task number inside the launch.
-template <bool FAST, bool PIPE>
+template <bool FAST, int PIPE>
 __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task_begin, int t, int64_t blk0, int64_t rec0, bool single, int chunk,
                                          double *X, int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
@@ -436,7 +518,7 @@ __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task_begi
         bend = B.task_ptr[task_begin + t + 1];
     }
     for (; b < bend; ++b) {
-        const Prologue R = load_prologue<PIPE>(B, rec0 + (b - blk0), lane);
+        const Prologue R = load_prologue<PIPE == 1>(B, rec0 + (b - blk0), lane);
         const BlockHeader h = header_of(R);
         switch (h.rc) {
             case 16: run_block_mfma<FAST, PIPE>(h, R, B, X, ldx, S, lds, cw, nrhs, lane); break;
@@ -459,7 +541,7 @@ __device__ __forceinline__ void split_item(int q, int n, int nchunks, int &blk, 
 
 // W wavefronts (w = 0..W-1) share one matrix-core block: contiguous ranges of its stages each, partial accumulators
 // meet in LDS (red: (W - 1) x 8 KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
-template <int W, bool FAST, bool PIPE>
+template <int W, bool FAST, int PIPE>
 __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t rec, int chunk, int w, double *red, double *X,
                                           int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
@@ -468,7 +550,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
     BlockHeader h;
     PanelCtx c;
     if (valid) {
-        const Prologue R = load_prologue<PIPE>(B, rec + w, lane);  // this wavefront's record of the block
+        const Prologue R = load_prologue<PIPE == 1>(B, rec + w, lane);  // this wavefront's record of the block
         h = header_of(R);
         c = make_ctx(h, B, X, ldx, S, lds, chunk * 64, nrhs, lane);
         const int nst = h.nsrc >> 4;
@@ -523,8 +605,8 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
     }
 }
 
-template <bool FAST, bool PIPE>
-__global__ __launch_bounds__(512, PIPE ? 2 : 4) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
+template <bool FAST, int PIPE>
+__global__ __launch_bounds__(512, PIPE == 1 ? 2 : 4) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
                                                     int nchunks)
 {
     extern __shared__ double red[];  // 7 x 8 KiB

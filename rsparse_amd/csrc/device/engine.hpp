@@ -165,6 +165,7 @@ constexpr i64 kTaskEntriesSingle = 512;
 constexpr i64 kLeanLaunchWorkgroups = 128;  // levels with at least this many 512-thread workgroups run the lean variant
 constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 right-hand sides: 3 parts are 2 % faster but re-read the
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)
+constexpr i64 kLeanMode = 2;  // lean variant of solve_level: 0 = one 16-source stage, 2 = two alternating 8-source half stages
 constexpr i64 kLeanLaunchWorkgroupsSingle = 128;  // the same switch for a single right-hand side (deep-fetch gather)
 constexpr i64 kSmallLaunchWaves = 2048;  // small-block tasks of a level get their own launch from this many wavefronts
 

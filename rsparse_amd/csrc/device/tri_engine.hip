@@ -283,8 +283,9 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             const unsigned wgs = (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
             // few workgroups: latency counts, pipelined variant; many: the lean variant at twice the occupancy
             const bool pipe = wgs < (unsigned)(nrhs == 1 ? lean_wgs_single : lean_wgs);
-            auto kernel = fast ? (pipe ? dev::solve_level<true, true> : dev::solve_level<true, false>)
-                               : (pipe ? dev::solve_level<false, true> : dev::solve_level<false, false>);
+            static const i64 lean_mode = env_or("RSP_LEAN_MODE", kLeanMode);  // 0: one full stage, 2: two alternating half stages
+            auto kernel = fast ? (pipe ? dev::solve_level<true, 1> : lean_mode == 2 ? dev::solve_level<true, 2> : dev::solve_level<true, 0>)
+                               : (pipe ? dev::solve_level<false, 1> : lean_mode == 2 ? dev::solve_level<false, 2> : dev::solve_level<false, 0>);
             hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, nchunks);
             done += wgs;
         }

@@ -1,6 +1,6 @@
 """Per-kernel totals and the slowest launches of the LAST factorisation in a rocprofv3 kernel trace (csv)."""
-import csv, sys, glob, collections
-f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
+import os, csv, sys, glob, collections
+f = sorted(glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True), key=os.path.getmtime)[-1]
 rows = [r for r in csv.DictReader(open(f)) if 'chol_' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last factorisation = after the last chol_scatter_A

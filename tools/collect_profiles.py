@@ -3,7 +3,7 @@ usage: collect_profiles.py <tag> <stats_dir> <bench.json of that run> [<fetch_di
 The LAST bench step is the span from the (2 x PARTS)-th-to-last solve_clusters launch to the last one: a step solves PARTS
 column parts (pair pipeline, engine.hpp kPairParts), each with one cluster launch in lsolve (its first) and one in ltsolve
 (its last)."""
-import csv, glob, json, os, sys, collections
+import os, csv, glob, json, os, sys, collections
 
 PARTS = int(os.environ.get("RSP_PAIR_PARTS", "2"))
 
@@ -20,18 +20,18 @@ def last_step(rows, key):
 
 out = {"tag": tag, "config": bench["config"], "ms_per_step_under_profiler": bench["ms_per_step"],
        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rhs 0 --skip-extras"}
-f = glob.glob(stats_dir + '/**/*_kernel_stats.csv', recursive=True)[0]
+f = sorted(glob.glob(stats_dir + '/**/*_kernel_stats.csv', recursive=True), key=os.path.getmtime)[-1]
 rows = [r for r in csv.DictReader(open(f)) if 'rsp::dev' in r['Name']]
 with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as g:
     w = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
     w.writeheader()
     w.writerows(rows)
-f = glob.glob(stats_dir + '/**/*_kernel_trace.csv', recursive=True)[0]
+f = sorted(glob.glob(stats_dir + '/**/*_kernel_trace.csv', recursive=True), key=os.path.getmtime)[-1]
 last = last_step([r for r in csv.DictReader(open(f)) if ours(r['Kernel_Name'])], lambda r: int(r['Start_Timestamp']))
 by = collections.defaultdict(lambda: [0, 0.0])
 for r in last:
     nm = r['Kernel_Name']
-    k = 'solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else 'solve_level<pipelined>' if ', true>' in nm else 'solve_level<lean>'
+    k = 'solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else 'solve_level<pipelined>' if ', 1>' in nm else 'solve_level<lean>'
     by[k][0] += 1
     by[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 out["step"] = {"launches": len(last),
@@ -40,7 +40,7 @@ out["step"] = {"launches": len(last),
                "span_us": round((int(last[-1]['End_Timestamp']) - int(last[0]['Start_Timestamp'])) / 1e3, 1)}
 if len(sys.argv) > 5:
     def total(d, name):
-        f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+        f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
         rs = last_step([r for r in csv.DictReader(open(f)) if r['Counter_Name'] == name and ours(r['Kernel_Name'])], lambda r: int(r['Dispatch_Id']))
         return sum(float(r['Counter_Value']) for r in rs), len(rs)
     (fetch_kb, n1), (write_kb, n2) = total(sys.argv[4], 'FETCH_SIZE'), total(sys.argv[5], 'WRITE_SIZE')

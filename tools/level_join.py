@@ -1,12 +1,12 @@
 """Join RSP_DUMP_LEVELS output with a rocprofv3 kernel trace of a NON-overlapped run (RSP_PAIR_OVERLAP=0):
 per level: work (matrix-core stages, vector entries, cluster count), launches and their durations."""
-import csv, glob, re, sys
+import os, csv, glob, re, sys
 dump, prof, nchunks = sys.argv[1], sys.argv[2], int(sys.argv[3])
 levels = []
 for line in open(dump):
     m = re.match(r"L(\d+) tasks (\d+)/(\d+)/(\d+)/(\d+) blocks (\d+) rows (\d+) mfma_stages (\d+) max (\d+) vec_blocks (\d+) vec_entries (\d+) clusters (\d+)", line)
     if m: levels.append([int(x) for x in m.groups()])
-f = glob.glob(prof + '/**/*_kernel_trace.csv', recursive=True)[0]
+f = sorted(glob.glob(prof + '/**/*_kernel_trace.csv', recursive=True), key=os.path.getmtime)[-1]
 rows = [r for r in csv.DictReader(open(f)) if 'solve_level' in r['Kernel_Name'] or 'solve_clusters' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # expected launches of one step (lsolve levels then ltsolve levels)

@@ -1,6 +1,6 @@
 """Per-launch durations of the last bench step from a rocprofv3 kernel trace (csv)."""
-import csv, sys, glob
-f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
+import os, csv, sys, glob
+f = sorted(glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True), key=os.path.getmtime)[-1]
 n = int(sys.argv[2])  # launches per step
 rows = [r for r in csv.DictReader(open(f)) if 'solve_level' in r['Kernel_Name'] or 'solve_clusters' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))

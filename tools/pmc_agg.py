@@ -1,13 +1,13 @@
 """Sum rocprofv3 --pmc counters per kernel over the last bench step(s): usage pmc_agg.py <dir> [<dir> ...]"""
-import csv, glob, sys, collections
+import os, csv, glob, sys, collections
 for d in sys.argv[1:]:
-    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.Counter()
     for r in csv.DictReader(open(f)):
         nm = r['Kernel_Name']
         if 'rsp::dev::solve' not in nm: continue
-        k = 'clusters' if 'clusters' in nm else 'small' if 'small' in nm else 'pipe' if ', true>' in nm else 'lean' if 'solve_level<' in nm else nm[:30]
+        k = 'clusters' if 'clusters' in nm else 'small' if 'small' in nm else 'pipe' if ', 1>' in nm else 'lean' if 'solve_level<' in nm else nm[:30]
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         n[(k, r['Counter_Name'])] += 1
     for k in acc:
