@@ -186,7 +186,7 @@ struct BlockProgram {
     i64 scratch_rows = 0;
     i64 big_chains = 0, inverted_rows = 0, padded_entries = 0, cluster_rows = 0, cluster_entries = 0;
 };
-constexpr i64 kBigChain = 32;        // chains longer than this are replaced by their inverse
+constexpr i64 kBigChain = 24;        // chains longer than this are replaced by their inverse
 constexpr i64 kMaxChain = 1024;      // ... in pieces of at most this many unknowns (host cost O(w^3) per piece)
 constexpr i64 kSplitSources = 64;    // matrix-core blocks with at least this many sources are split over 4 wavefronts,
                                      // with more than 4x this over 8
