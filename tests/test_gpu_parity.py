@@ -398,6 +398,7 @@ def test_cholsol_batch_large_systems_take_the_ordinary_path():
         assert rel_inf(got[s], one) <= 1e-11
 
 
+@pytest.mark.skipif(__import__("os").environ.get("RSP_CHOL_GROUPED") == "0", reason="the source-owned variant sums with atomics")
 def test_chol_is_bit_reproducible():
     """The numeric factorisation owns every target tile with one wavefront and sums in a host-fixed order (no atomics):
     two factorisations of the same matrix give the same bits, as the sequential reference does."""
