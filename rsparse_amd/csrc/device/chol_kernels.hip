@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
                 const double dtt = readlane_f64(d[t], t);
                 if (dtt <= 0.0 && lane == 0 && blk <= 0) atomicMin(A.status, I.c0 + t);
                 const double l = sqrt(dtt);
-                d[t] = lane == t ? l : d[t] / l;  // L(k,i) = x_i / L(i,i), lib.rs:310
+                const double rl = 1.0 / l;        // L(k,i) = x_i / L(i,i) (lib.rs:310) as a multiplication by the
+                d[t] = lane == t ? l : d[t] * rl;  // reciprocal: one division per column instead of one per entry
 #pragma unroll
                 for (int jj = t + 1; jj < 32; ++jj)
                     if (jj < w) d[jj] -= d[t] * readlane_f64(d[t], jj);  // above the diagonal (lane < jj) this collects values nothing reads
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
                 if (!parked) A.Lx[panel_entry(P.base, len0, lane, t)] = d[t];
                 else if (blk == 0) A.dbuf[(int64_t)P.dslot * 1024 + lane * 32 + t] = d[t];
             }
-            if (lane < 32) D[lane][t] = d[t];
+            if (lane < 32) D[lane][t] = lane == t ? 1.0 / d[t] : d[t];  // the row solve multiplies by the reciprocal diagonal
         }
         if (blk < 0) return;
     } else {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = 64 * k + lane;
-            D[idx & 31][idx >> 5] = dv[k];
+            D[idx & 31][idx >> 5] = ((idx & 31) == (idx >> 5) && (idx >> 5) < w) ? 1.0 / dv[k] : dv[k];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
                 double v = x[t];
 #pragma unroll
                 for (int u = 0; u < t; ++u) v -= x[u] * D[t][u];
-                x[t] = v / D[t][t];
+                x[t] = v * D[t][t];
             }
         }
 #pragma unroll
