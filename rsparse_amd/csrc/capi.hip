@@ -26,6 +26,7 @@ struct rsp_chol {
 struct rsp_lu {
     LuFactors f;
     std::unique_ptr<TriSolver> lower, upper;  // built on first solve
+    bool single_use = false;                  // lusol: one solve, then dropped
 };
 
 namespace {
@@ -82,6 +83,7 @@ int one_shot(const rsp_csc_f64 *T, int kind, double *x)
         if (int st = require_device()) return st;
         TriSolver s;
         if (int st = s.analyze(view_of(T), kind)) return st;
+        s.set_single_use();
         s.solve_host(x, T->n, 1);
         return (int)RSP_OK;
     });
@@ -363,6 +365,7 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     const double t1 = clock();
     if (st == RSP_OK) st = rsp_chol_factor_f64(A, S, &F);  // numeric Cholesky (GPU)
     const double t2 = clock();
+    if (st == RSP_OK) F->f.set_single_use(true);         // one solve, then the factor is dropped
     if (st == RSP_OK) st = rsp_chol_solve_f64(F, b, A->n, 1);  // P, lsolve, ltsolve, P' (GPU)
     const double t3 = clock();
     rsp_chol_free(F);
@@ -390,6 +393,7 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
             for (int64_t s = 0; s < nsys; ++s) {
                 CscView V = view_of(A);
                 V.x = Ax_all + s * nnz;
+                F.set_single_use(true);
                 const int st = F.factorize(V);
                 if (st == kOk) F.solve_host(B + s * n, n, 1);
                 else if (st != kNotPositiveDefinite) return st;
@@ -465,7 +469,7 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
         const int64_t n = N->f.L.n;
         if (!N->lower) {
             std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
-            if (int st = analyze_pair(*lo, N->f.L.view(), RSP_LSOLVE, *up, N->f.U.view(), RSP_USOLVE)) return st;
+            if (int st = analyze_pair(*lo, N->f.L.view(), RSP_LSOLVE, *up, N->f.U.view(), RSP_USOLVE, N->single_use)) return st;
             N->lower = std::move(lo);
             N->upper = std::move(up);
         }
@@ -494,6 +498,7 @@ int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol)
     rsp_lu *N = nullptr;
     int st = rsp_sqr_lu(A, order, &S);               // ordering (host)
     if (st == RSP_OK) st = rsp_lu_f64(A, S, tol, &N);  // numeric LU (host, pivot sequence bit-exact)
+    if (st == RSP_OK) N->single_use = true;
     if (st == RSP_OK) st = rsp_lu_solve_f64(N, S, b, A->n, 1);  // lsolve + usolve (GPU)
     rsp_lu_free(N);
     rsp_symb_free(S);

@@ -583,7 +583,7 @@ void CholFactor::build_solvers()
     d_Lx.download(Lx.data(), Lx.size());
     const CscView L{n_, n_, Lp_.data(), Li_.data(), Lx.data()};
     std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
-    if (analyze_pair(*lo, L, 0, *up, L, 1) != kOk) throw DeviceError("factor is not a valid triangular matrix");
+    if (analyze_pair(*lo, L, 0, *up, L, 1, single_use_) != kOk) throw DeviceError("factor is not a valid triangular matrix");
     lower_ = std::move(lo);
     upper_ = std::move(up);
 }
@@ -632,8 +632,14 @@ void CholFactor::solve_host(double *B, i64 ldb, i64 nrhs)
     if (nrhs <= 0 || n_ == 0) return;
     DeviceBuffer<double> d((size_t)n_ * (size_t)nrhs);
     RSP_HIP(hipMemcpy2D(d.get(), n_ * sizeof(double), B, ldb * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyHostToDevice));
+    const bool timing = getenv("RSP_TIMING") != nullptr;
+    const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (timing) build_solvers();  // so that the figure below is the solve alone
+    if (timing) RSP_HIP(hipDeviceSynchronize());
+    const double t0 = clock();
     solve_device(d.get(), 0, n_, nrhs, true, nullptr);
     RSP_HIP(hipDeviceSynchronize());
+    if (timing) fprintf(stderr, "chol solve: %lld right-hand side(s) on the device %.3fs\n", (long long)nrhs, clock() - t0);
     RSP_HIP(hipMemcpy2D(B, ldb * sizeof(double), d.get(), n_ * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyDeviceToHost));
 }
 

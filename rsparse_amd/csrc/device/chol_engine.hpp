@@ -40,12 +40,14 @@ class CholFactor {
     i64 n() const { return n_; }
     i64 lnz() const { return lnz_; }
     double factor_ms() const { return factor_ms_; }
+    // the factor is solved against once and discarded (cholsol): see TriSolver::set_single_use()
+    void set_single_use(bool v) { single_use_ = v; }
 
    private:
     void build_solvers();
 
     i64 n_ = 0, lnz_ = 0, annz_ = 0;
-    bool has_pinv_ = false;
+    bool has_pinv_ = false, single_use_ = false;
     std::vector<i64> pinv_, Lp_, Li_;  // host copies (Li_ as the reference stores it)
     double flops_ = 0.0;
     double factor_ms_ = 0.0;

@@ -83,6 +83,14 @@ struct TriProgram {
     }
 };
 
+// Host image of a TriProgram before its upload (built without any device call, so it can be made on a worker thread).
+struct TriProgramHost {
+    i64 ntasks = 0, nlevels = 0, longest_task = 0;
+    std::vector<int32_t> task_ptr, op_row, op_ptr, ent_idx;
+    std::vector<double> op_diag, ent_val;
+    std::vector<std::pair<int, int>> levels;
+};
+
 // The blocked multi-right-hand-side programme (host/blocked.cpp) resident on the device.
 struct BlockedProgram {
     i64 ntasks = 0, nlevels = 0, nblocks = 0, scratch_rows = 0, big_chains = 0, inverted_rows = 0, padded_entries = 0;
@@ -134,10 +142,16 @@ class TriSolver {
     // pieces of the multi-right-hand-side path that solve_pair_device drives on two streams
     void prepare_blocked(i64 total_cols);
     void stage_blocked();  // host-only: builds the multi-RHS programme ahead of its upload
+    // The caller analyses, solves ONE vector and discards (cholsol, lusol, the one-shot lsolve...): take the plain level
+    // programme (one launch per dependency level, nothing to build) when its launches cost less than building the
+    // blocked programme for a single use.  Handles that solve many times never call this.
+    void set_single_use();
+    bool single_use_levels() const { return single_use_levels_; }
     void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy);
 
    private:
     void build_program(i64 max_task_entries, TriProgram &P);
+    TriProgramHost stage_program(i64 max_task_entries) const;  // host half of build_program
     void run_multi(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
     void run_blocked(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
     void build_blocked();
@@ -148,15 +162,17 @@ class TriSolver {
     std::vector<i64> level_of_row_;
     TriProgram multi_, single_;
     BlockedProgram blocked_;
-    bool have_multi_ = false, have_single_ = false, have_blocked_ = false;
+    bool have_multi_ = false, have_single_ = false, have_blocked_ = false, single_use_levels_ = false;
     std::unique_ptr<BlockProgram> staged_;
+    std::unique_ptr<TriProgramHost> staged_single_;  // set_single_use(): the level programme, ready for upload
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
 };
 
 // first.solve then second.solve on one row-major device block, column halves pipelined over two streams
 // a.analyze(Ta, kind_a) and b.analyze(Tb, kind_b) plus both programme builds, on two host threads
-int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, const CscView &Tb, int kind_b);
+// single_use: see TriSolver::set_single_use()
+int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, const CscView &Tb, int kind_b, bool single_use = false);
 void solve_pair_device(TriSolver &first, TriSolver &second, double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
 
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)

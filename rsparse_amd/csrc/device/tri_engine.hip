@@ -35,41 +35,59 @@ int TriSolver::analyze(const CscView &T, int kind)
     return kOk;
 }
 
-void TriSolver::build_program(i64 max_task_entries, TriProgram &P)
+TriProgramHost TriSolver::stage_program(i64 max_task_entries) const
 {
     const Schedule S = build_schedule(G_, max_task_entries);
+    TriProgramHost H;
     const i64 ntasks = (i64)S.task_first.size();
-    std::vector<int32_t> task_ptr(ntasks + 1, 0), op_row(n_), op_ptr(n_ + 1, 0), ent_idx(G_.idx.size());
-    std::vector<double> op_diag(n_), ent_val(G_.val.size());
+    H.task_ptr.assign(ntasks + 1, 0);
+    H.op_row.resize(n_);
+    H.op_ptr.assign(n_ + 1, 0);
+    H.ent_idx.resize(G_.idx.size());
+    H.op_diag.resize(n_);
+    H.ent_val.resize(G_.val.size());
     i64 op = 0, ent = 0;
     for (i64 t = 0; t < ntasks; ++t) {
-        task_ptr[t] = (int32_t)op;
+        H.task_ptr[t] = (int32_t)op;
         for (i64 s = 0; s < S.task_rows[t]; ++s) {
             const i64 r = G_.descending ? S.task_first[t] - s : S.task_first[t] + s;
-            op_row[op] = (int32_t)r;
-            op_diag[op] = G_.diag[r];
-            op_ptr[op] = (int32_t)ent;
+            H.op_row[op] = (int32_t)r;
+            H.op_diag[op] = G_.diag[r];
+            H.op_ptr[op] = (int32_t)ent;
             const i64 len = G_.ptr[r + 1] - G_.ptr[r];
-            std::copy(G_.idx.begin() + G_.ptr[r], G_.idx.begin() + G_.ptr[r + 1], ent_idx.begin() + ent);
-            std::copy(G_.val.begin() + G_.ptr[r], G_.val.begin() + G_.ptr[r + 1], ent_val.begin() + ent);
+            std::copy(G_.idx.begin() + G_.ptr[r], G_.idx.begin() + G_.ptr[r + 1], H.ent_idx.begin() + ent);
+            std::copy(G_.val.begin() + G_.ptr[r], G_.val.begin() + G_.ptr[r + 1], H.ent_val.begin() + ent);
             ent += len;
             ++op;
         }
     }
-    task_ptr[ntasks] = (int32_t)op;
-    op_ptr[n_] = (int32_t)ent;
-    P.ntasks = ntasks;
-    P.nlevels = (i64)S.level_ptr.size() - 1;
-    P.longest_task = S.longest_task;
-    P.levels.clear();
-    for (i64 l = 0; l < P.nlevels; ++l)
-        P.levels.emplace_back((int)S.level_ptr[l], (int)(S.level_ptr[l + 1] - S.level_ptr[l]));
-    P.task_ptr.upload(task_ptr);
-    P.op_row.upload(op_row);
-    P.op_ptr.upload(op_ptr);
-    P.op_diag.upload(op_diag);
-    P.ent_idx.upload(ent_idx);
-    P.ent_val.upload(ent_val);
+    H.task_ptr[ntasks] = (int32_t)op;
+    H.op_ptr[n_] = (int32_t)ent;
+    H.ntasks = ntasks;
+    H.nlevels = (i64)S.level_ptr.size() - 1;
+    H.longest_task = S.longest_task;
+    for (i64 l = 0; l < H.nlevels; ++l) H.levels.emplace_back((int)S.level_ptr[l], (int)(S.level_ptr[l + 1] - S.level_ptr[l]));
+    return H;
+}
+
+static void upload_program(TriProgramHost &H, TriProgram &P)
+{
+    P.ntasks = H.ntasks;
+    P.nlevels = H.nlevels;
+    P.longest_task = H.longest_task;
+    P.levels = std::move(H.levels);
+    P.task_ptr.upload(H.task_ptr);
+    P.op_row.upload(H.op_row);
+    P.op_ptr.upload(H.op_ptr);
+    P.op_diag.upload(H.op_diag);
+    P.ent_idx.upload(H.ent_idx);
+    P.ent_val.upload(H.ent_val);
+}
+
+void TriSolver::build_program(i64 max_task_entries, TriProgram &P)
+{
+    TriProgramHost H = stage_program(max_task_entries);
+    upload_program(H, P);
 }
 
 static dev::TriArrays arrays_of(const TriProgram &P)
@@ -116,15 +134,28 @@ void TriSolver::stage_blocked()
         build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots))));
 }
 
+void TriSolver::set_single_use()
+{
+    // measured at C2 (7 307 row levels, 47.5 M entries): a level launch costs about 6 us, the programme build about 20 ns per
+    // entry; the levels win when they are cheaper by a factor of two.  RSP_SINGLE_USE=0 always keeps the blocked
+    // programme, =1 always takes the levels (read per call: the tests run both ways in one process).
+    const char *mode = getenv("RSP_SINGLE_USE");
+    if (mode && (mode[0] == '0' || mode[0] == '1')) single_use_levels_ = mode[0] == '1';
+    else single_use_levels_ = (double)num_row_levels_ * 6e-6 < (double)nnz_ * 1e-8;
+    // host half of the level programme right away: analyze_pair() calls this on its worker threads
+    if (single_use_levels_ && !have_single_ && !staged_single_) staged_single_.reset(new TriProgramHost(stage_program(kTaskEntriesSingle)));
+}
+
 // analyse two factors (or one factor in two directions) side by side on two host threads, programmes included
-int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, const CscView &Tb, int kind_b)
+int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, const CscView &Tb, int kind_b, bool single_use)
 {
     int sa = kOk, sb = kOk;
     std::exception_ptr ea, eb;
-    auto work = [](TriSolver &t, const CscView &T, int kind, int &st, std::exception_ptr &e) {
+    auto work = [single_use](TriSolver &t, const CscView &T, int kind, int &st, std::exception_ptr &e) {
         try {
             st = t.analyze(T, kind);
-            if (st == kOk) t.stage_blocked();
+            if (st == kOk && single_use) t.set_single_use();
+            if (st == kOk && !t.single_use_levels()) t.stage_blocked();
         } catch (...) {
             e = std::current_exception();
         }
@@ -352,8 +383,16 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i
 void TriSolver::run_single(double *x, hipStream_t stream)
 {
     if (!have_single_) {
-        build_program(kTaskEntriesSingle, single_);
+        const double t0 = now_s();
+        if (staged_single_) {
+            upload_program(*staged_single_, single_);
+            staged_single_.reset();
+        } else {
+            build_program(kTaskEntriesSingle, single_);
+        }
         have_single_ = true;
+        if (getenv("RSP_TIMING"))
+            fprintf(stderr, "tri level programme: %.2fs, %lld levels, %lld tasks\n", now_s() - t0, (long long)single_.nlevels, (long long)single_.ntasks);
     }
     const dev::TriArrays A = arrays_of(single_);
     const int wpb = 4;
@@ -371,7 +410,7 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
         // one right-hand side: a column vector is its own row-major n x 1 block.  The blocked programme needs ~170
         // launches per sweep where the plain level programme needs one per dependency level (thousands).
         static const bool single_levels = getenv("RSP_TRI_SINGLE") && getenv("RSP_TRI_SINGLE")[0] == '1';
-        if (single_levels) run_single(dX, stream);
+        if (single_levels || single_use_levels_) run_single(dX, stream);
         else run_blocked(dX, 1, 1, stream);
         return;
     }

@@ -190,6 +190,38 @@ def test_trisolve_single_rhs_vs_oracle(kind, fac):
     assert rel_inf(got, want) <= REL_X
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("kind,fac", KINDS)
+def test_one_shot_trisolve_both_programmes(kind, fac, mode, monkeypatch):
+    """One-shot calls choose between the blocked programme and the plain level programme by a cost rule
+    (TriSolver::set_single_use); RSP_SINGLE_USE forces either, and both must give the oracle's result."""
+    monkeypatch.setenv("RSP_SINGLE_USE", mode)
+    T = factors()[fac]
+    b = 2.0 * synth.splitmix64(6, T[0]) - 1.0
+    want = orc.trisolve(kind, T, b)
+    got = b.copy()
+    getattr(rs, kind)(T, got)
+    assert rel_inf(got, want) <= REL_X
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_one_shot_drivers_both_programmes(mode, monkeypatch):
+    monkeypatch.setenv("RSP_SINGLE_USE", mode)
+    A = synth.laplacian_2d(40, 33)
+    b = orc.gaxpy(A, 2.0 * synth.splitmix64(1, A[0]) - 1.0, np.zeros(A[0]))
+    for order in (0, -1):
+        st, want = orc.cholsol(A, b, order)
+        got = b.copy()
+        rs.cholsol(A, got, order)
+        assert st == orc.OK and rel_inf(got, want) <= REL_X
+    B = synth.banded_unsymmetric(2000, band=20)
+    c = synth.splitmix64(5, B[0])
+    st, want = orc.lusol(B, c, 1, 1.0)
+    got = c.copy()
+    rs.lusol(B, got, 1, 1.0)
+    assert st == orc.OK and rel_inf(got, want) <= REL_X
+
+
 @pytest.mark.parametrize("kind,fac", KINDS)
 @pytest.mark.parametrize("nrhs", [2, 7, 64, 130, 256])
 def test_trisolve_multi_rhs_vs_oracle(kind, fac, nrhs):
