@@ -5,6 +5,7 @@
 #include <climits>
 
 #include "chol_engine.hpp"
+#include "../host/parallel.hpp"
 
 namespace rsp {
 
@@ -271,33 +272,38 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
             for (size_t x = 0; x < gen.size(); ++x)
                 order[at[gen[x].level]++] = {((uint64_t)(uint32_t)gen[x].s << 32) | (uint32_t)gen[x].r16, (uint32_t)x};
         }
-        for (i64 l = 0; l < nlevels_; ++l) std::sort(order.begin() + lv_fill[l], order.begin() + lv_fill[l + 1]);
+        for (i64 l = 0; l < nlevels_; ++l) parallel_sort(order.begin() + lv_fill[l], order.begin() + lv_fill[l + 1]);
         std::vector<Key> keys(gen.size());
-        for (size_t x = 0; x < gen.size(); ++x) keys[x] = gen[order[x].second];
         subs.resize(keys.size());
+        // the records are independent of each other (host threads); the groups are formed in order afterwards
+        parallel_ranges((i64)keys.size(), 1 << 16, [&](i64 xb, i64 xe) {
+            for (i64 x = xb; x < xe; ++x) {
+                keys[x] = gen[order[x].second];
+                const Key &key = keys[x];
+                const Pair &p = pairs[key.pair];
+                const i64 sc = super[p.sup];
+                dev::CholSub &u = subs[x];
+                u.src_base = Lp_[sc];
+                u.len_d = (int32_t)(Lp_[sc + 1] - Lp_[sc]);
+                u.rs = prow[p.d];
+                u.q0 = p.q0;
+                u.mask = p.mask;
+                u.t_begin = p.t_begin;
+                u.t_end = p.t_end;
+                u.qa = key.qa;
+                u.pad = 0;
+                u.pad2[0] = u.pad2[1] = 0;
+                uint8_t map[16];
+                std::fill(map, map + 16, (uint8_t)0xff);
+                const int32_t *rp = rel.data() + rel_off[key.pair];
+                for (i64 q = key.qa; q < prow[p.d] && (rp[q - p.q0] >> 4) == key.r16; ++q)
+                    map[rp[q - p.q0] & 15] = (uint8_t)(q - key.qa);  // at most 16 rows share a tile
+                std::memcpy(u.rowmap, map, 16);
+            }
+        });
         for (size_t x = 0; x < keys.size(); ++x) {
             const Key &key = keys[x];
             const Pair &p = pairs[key.pair];
-            const i64 sc = super[p.sup];
-            dev::CholSub &u = subs[x];
-            u.src_base = Lp_[sc];
-            u.len_d = (int32_t)(Lp_[sc + 1] - Lp_[sc]);
-            u.rs = prow[p.d];
-            u.q0 = p.q0;
-            u.mask = p.mask;
-            u.t_begin = p.t_begin;
-            u.t_end = p.t_end;
-            u.qa = key.qa;
-            u.pad = 0;
-            u.pad2[0] = u.pad2[1] = 0;
-            uint8_t map[16];
-            std::fill(map, map + 16, (uint8_t)0xff);
-            const int32_t *rp = rel.data() + rel_off[key.pair];
-            for (i64 q = key.qa; q < prow[p.d] && (rp[q - p.q0] >> 4) == key.r16; ++q) {
-                if (q - key.qa > 254) return kBadInput;  // cannot happen: at most 16 rows share a tile
-                map[rp[q - p.q0] & 15] = (uint8_t)(q - key.qa);
-            }
-            std::memcpy(u.rowmap, map, 16);
             const bool fresh = x == 0 || keys[x - 1].level != key.level || keys[x - 1].s != key.s || keys[x - 1].r16 != key.r16;
             if (fresh) {
                 groups.push_back(dev::CholGroup{Lp_[c0[p.s]], (i64)x, (c0[p.s + 1] - c0[p.s]) + prow[p.s], c0[p.s + 1] - c0[p.s], key.r16, 0});

@@ -14,24 +14,13 @@
 #include <cstdio>
 #include <thread>
 
+#include "parallel.hpp"
 #include "sparse.hpp"
 
 namespace rsp {
 namespace {
 
 constexpr int32_t kNone = BlockProgram::kNone;
-
-// 1, 2, 4: vector path (registers per lane); more than 4 unknowns: a 16-row matrix-core block (MFMA 16x16x4 f64)
-// worker threads for the O(w^3) inverses: RSP_HOST_THREADS, else OMP_NUM_THREADS (the GPU boxes set it to their CPU
-// share), else the hardware's count capped at 16
-inline i64 host_threads()
-{
-    for (const char *name : {"RSP_HOST_THREADS", "OMP_NUM_THREADS"})
-        if (const char *e = std::getenv(name))
-            if (std::atoll(e) > 0) return std::min<i64>(std::atoll(e), 64);
-    const unsigned hw = std::thread::hardware_concurrency();
-    return std::max<i64>(1, std::min<i64>(hw ? hw : 1, 16));
-}
 
 struct StageClock {  // RSP_TIMING=1: where the host time of a programme build goes (stderr)
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -44,6 +33,7 @@ struct StageClock {  // RSP_TIMING=1: where the host time of a programme build g
     }
 };
 
+// 1, 2, 4: vector path (registers per lane); more than 4 unknowns: a 16-row matrix-core block (MFMA 16x16x4 f64)
 inline int class_of(i64 rows) { return rows <= 1 ? 1 : rows <= 2 ? 2 : rows <= 4 ? 4 : 16; }
 
 struct Triple {
