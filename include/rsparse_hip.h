@@ -94,6 +94,12 @@ void rsp_tri_free(rsp_tri *h);
 int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
                              double *max_rel_error);
 
+/* Host-only self-test of the threaded helpers the analyses use (host/parallel.hpp; debug aid, no reference counterpart,
+ * no GPU): sorts `count` pseudo-random keys (seeded) with the threaded sort and fills an array over threaded ranges, on
+ * `threads` host threads (<= 0: the library's default), and compares with the sequential result.
+ * Returns RSP_OK when both agree, RSP_BAD_INPUT otherwise. */
+int rsp_selftest_host_threads(int64_t count, int threads, uint64_t seed);
+
 /* ---- symbolic analysis (host CPU) -------------------------------------------------------------
  * rsparse::schol (src/lib.rs:968-986) and the LU branch of rsparse::sqr (src/lib.rs:1114-1119,1134-1137).
  * rsp_symb mirrors rsparse::data::Symb (src/data.rs:1022-1038). */

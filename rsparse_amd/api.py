@@ -67,6 +67,7 @@ def lib():
             "rsp_tri_levels": (cint, [vp, vp]),
             "rsp_tri_free": (None, [vp]),
             "rsp_tri_validate_program": (cint, [csc, cint, i64, cint, vp, vp]),
+            "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_sqr_lu": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_symb_from_parts": (cint, [i64, vp, vp, vp, vp, C.POINTER(vp)]),

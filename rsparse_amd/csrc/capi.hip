@@ -5,12 +5,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <string>
 #include <utility>
+#include <vector>
 #include <new>
 
 #include "../../include/rsparse_hip.h"
 #include "device/chol_engine.hpp"
 #include "device/engine.hpp"
+#include "host/parallel.hpp"
 
 using namespace rsp;
 
@@ -195,6 +199,39 @@ int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row)
 }
 
 void rsp_tri_free(rsp_tri *h) { delete h; }
+
+int rsp_selftest_host_threads(int64_t count, int threads, uint64_t seed)
+{
+    if (count < 0) return RSP_BAD_INPUT;
+    return guarded([&] {
+        const char *old = getenv("RSP_HOST_THREADS");
+        const std::string keep = old ? old : "";
+        if (threads > 0) setenv("RSP_HOST_THREADS", std::to_string(threads).c_str(), 1);
+        std::vector<std::pair<uint64_t, uint32_t>> a((size_t)count);
+        uint64_t z = seed;
+        for (int64_t k = 0; k < count; ++k) {  // SplitMix64, keys with many ties, unique ordinals
+            z += 0x9e3779b97f4a7c15ull;
+            uint64_t v = z;
+            v = (v ^ (v >> 30)) * 0xbf58476d1ce4e5b9ull;
+            v = (v ^ (v >> 27)) * 0x94d049bb133111ebull;
+            a[k] = {(v ^ (v >> 31)) % 1000, (uint32_t)k};
+        }
+        auto b = a;
+        std::sort(b.begin(), b.end());
+        parallel_sort(a.begin(), a.end());
+        std::vector<int64_t> f((size_t)count, -1);
+        parallel_ranges(count, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) f[k] += k + 2;  // every index exactly once -> k + 1
+        });
+        bool ok = a == b;
+        for (int64_t k = 0; k < count && ok; ++k) ok = f[k] == k + 1;
+        if (threads > 0) {
+            if (old) setenv("RSP_HOST_THREADS", keep.c_str(), 1);
+            else unsetenv("RSP_HOST_THREADS");
+        }
+        return ok ? (int)RSP_OK : (int)RSP_BAD_INPUT;
+    });
+}
 
 int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
                              double *max_rel_error)

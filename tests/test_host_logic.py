@@ -215,3 +215,10 @@ def test_batched_cholsol_rejects_bad_input_and_needs_a_gpu():
     if not torch.cuda.is_available():  # no CPU fallback: the numeric path fails loudly without a GPU
         with pytest.raises(rs.DeviceError):
             rs.cholsol_batch(A, vals, B, 0)
+
+
+@pytest.mark.parametrize("count,threads", [(0, 4), (1, 4), (1000, 8), (200_000, 1), (200_000, 3), (1_000_000, 8), (1_000_003, 16)])
+def test_threaded_host_helpers_agree_with_sequential(count, threads):
+    """host/parallel.hpp (threaded sort and ranges used by the analyses): same result as the sequential code for any
+    thread count, including chunk counts that do not divide the input."""
+    assert rs.lib().rsp_selftest_host_threads(count, threads, 12345 + count) == 0
