@@ -324,7 +324,7 @@ int rsp_amd(const rsp_csc_f64 *A, int8_t order, int64_t *P, int *has_perm)
 
 // ---- Cholesky -----------------------------------------------------------------------------------
 
-int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F)
+static int chol_factor_impl(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F, bool single_use)
 {
     if (!sane_indices(A) || !S || !F || A->m != A->n || S->s.n != A->n || S->s.parent.size() != (size_t)A->n ||
         S->s.cp.size() != (size_t)A->n + 1)
@@ -333,12 +333,14 @@ int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F)
     return guarded([&] {
         if (int st = require_device()) return st;
         std::unique_ptr<rsp_chol> h(new rsp_chol);
-        if (int st = h->f.analyze(view_of(A), S->s)) return st;
+        if (int st = h->f.analyze(view_of(A), S->s, single_use)) return st;
         if (int st = h->f.factorize(view_of(A))) return st;
         *F = h.release();
         return (int)RSP_OK;
     });
 }
+
+int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F) { return chol_factor_impl(A, S, F, false); }
 
 int rsp_chol_f64(const rsp_csc_f64 *A, const rsp_symb *S, int64_t *Lp, uint64_t *Li, double *Lx)
 {
@@ -400,7 +402,7 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     const double t0 = clock();
     int st = rsp_schol(A, order, &S);                    // ordering and symbolic analysis (host)
     const double t1 = clock();
-    if (st == RSP_OK) st = rsp_chol_factor_f64(A, S, &F);  // numeric Cholesky (GPU)
+    if (st == RSP_OK) st = chol_factor_impl(A, S, &F, true);  // numeric Cholesky (GPU); one solve, then the factor is dropped
     const double t2 = clock();
     if (st == RSP_OK) F->f.set_single_use(true);         // one solve, then the factor is dropped
     if (st == RSP_OK) st = rsp_chol_solve_f64(F, b, A->n, 1);  // P, lsolve, ltsolve, P' (GPU)

@@ -9,8 +9,18 @@
 
 namespace rsp {
 
-int CholFactor::analyze(const CscView &A, const Symbolic &S)
+void CholFactor::join_pattern_jobs()
 {
+    for (auto &t : pat_thread_)
+        if (t.joinable()) t.join();
+}
+
+int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
+{
+    join_pattern_jobs();
+    pat_lower_.reset();
+    pat_upper_.reset();
+    single_use_ = single_use;
     double tmark = now_s();
     auto lap = [&](const char *what) {
         if (getenv("RSP_TIMING")) fprintf(stderr, "chol analyze: %s %.2fs\n", what, now_s() - tmark);
@@ -43,6 +53,21 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S)
     for (i64 j = 0; j < n_; ++j) {
         const double c = (double)(Lp_[j + 1] - Lp_[j]);
         flops_ += c * c;
+    }
+    if (single_use && lnz_ < INT32_MAX) {
+        // the solve phase needs the level structure of L in both directions, which depends on the pattern alone: start it
+        // now, beside the rest of this analysis and the factorisation (Lp_ and Li_ do not change any more)
+        pat_lower_.reset(new TriSolver);
+        pat_upper_.reset(new TriSolver);
+        for (int k = 0; k < 2; ++k)
+            pat_thread_[k] = std::thread([this, k] {
+                try {
+                    const CscView Lpat{n_, n_, Lp_.data(), Li_.data(), nullptr};
+                    pat_status_[k] = (k == 0 ? pat_lower_ : pat_upper_)->analyze(Lpat, k);
+                } catch (...) {
+                    pat_status_[k] = kBadInput;  // build_solvers() falls back to the full analysis
+                }
+            });
     }
 
     // ---- where every entry of A lands in L (C(lo,hi) -> L(hi,lo)); for duplicates the LAST one in the
@@ -585,9 +610,35 @@ void CholFactor::download(i64 *Lp, i64 *Li, double *Lx) const
 void CholFactor::build_solvers()
 {
     if (lower_) return;
+    join_pattern_jobs();
     std::vector<double> Lx((size_t)lnz_);
     d_Lx.download(Lx.data(), Lx.size());
     const CscView L{n_, n_, Lp_.data(), Li_.data(), Lx.data()};
+    if (pat_lower_ && pat_upper_ && pat_status_[0] == kOk && pat_status_[1] == kOk) {
+        // the patterns were analysed beside the factorisation: add the values, then stage what the solve will run
+        std::unique_ptr<TriSolver> lo = std::move(pat_lower_), up = std::move(pat_upper_);
+        const bool single = single_use_;
+        auto finish = [&L, single](TriSolver &t, std::exception_ptr &e) {
+            try {
+                t.set_values(L);
+                if (single) t.set_single_use();
+                if (!t.single_use_levels()) t.stage_blocked();
+            } catch (...) {
+                e = std::current_exception();
+            }
+        };
+        std::exception_ptr ea, eb;
+        std::thread other(finish, std::ref(*up), std::ref(eb));
+        finish(*lo, ea);
+        other.join();
+        if (ea) std::rethrow_exception(ea);
+        if (eb) std::rethrow_exception(eb);
+        lower_ = std::move(lo);
+        upper_ = std::move(up);
+        return;
+    }
+    pat_lower_.reset();
+    pat_upper_.reset();
     std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
     if (analyze_pair(*lo, L, 0, *up, L, 1, single_use_) != kOk) throw DeviceError("factor is not a valid triangular matrix");
     lower_ = std::move(lo);

@@ -12,6 +12,8 @@
 // The pattern of L (Lp == cp, diagonal first, rows ascending) is computed on the host exactly as the
 // reference lays it out, so the integer structure is bit-identical; values agree to rounding.
 #pragma once
+#include <thread>
+
 #include "engine.hpp"
 #include "chol_kernels.hip"
 
@@ -26,7 +28,9 @@ constexpr i64 kBatchMaxN = 16384;  // batched solve keeps the vector of a system
 class CholFactor {
    public:
     // symbolic work + uploads; needs only the pattern of A. kOk / kBadInput.
-    int analyze(const CscView &A, const Symbolic &S);
+    // single_use: the factor will be solved against once and dropped (cholsol); the pattern analysis of L for the
+    // triangular solves then starts on host threads as soon as the pattern of L is known, beside the rest of this call
+    int analyze(const CscView &A, const Symbolic &S, bool single_use = false);
     // numeric factorisation of values A.x (same pattern as analysed). kOk / kNotPositiveDefinite.
     int factorize(const CscView &A);
     // batched variant (same pattern, nsys value sets): see chol_engine.hip.  n must not exceed kBatchMaxN for solve_batch.
@@ -90,6 +94,18 @@ class CholFactor {
 
     std::unique_ptr<TriSolver> lower_, upper_;
     DeviceBuffer<double> work_;
+    // single use: the pattern analysis of L for the two sweeps, started by analyze() on two host threads (no device
+    // calls there); build_solvers() joins them and adds the values
+    std::unique_ptr<TriSolver> pat_lower_, pat_upper_;
+    int pat_status_[2] = {kOk, kOk};
+    std::thread pat_thread_[2];
+    void join_pattern_jobs();
+
+   public:
+    CholFactor() = default;
+    CholFactor(const CholFactor &) = delete;
+    CholFactor &operator=(const CholFactor &) = delete;
+    ~CholFactor() { join_pattern_jobs(); }
 };
 
 }  // namespace rsp

@@ -126,6 +126,9 @@ class TriSolver {
    public:
     // throws DeviceError; returns kOk / kBadInput
     int analyze(const CscView &T, int kind);
+    // T.x == nullptr analyses the pattern alone (no device call, any thread); set_values() with the same matrix and its
+    // values must follow before anything is solved or staged
+    void set_values(const CscView &T);
     // dX device pointer. layout: 0 column-major, 1 row-major (include/rsparse_hip.h).  Asynchronous on `stream`.
     void solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream_t stream);
     // X host column-major
@@ -158,6 +161,7 @@ class TriSolver {
     void run_single(double *x, hipStream_t stream);
 
     i64 n_ = 0, nnz_ = 0, num_row_levels_ = 0;
+    int kind_ = 0;
     GatherForm G_;  // kept on the host so the second program can be built lazily
     std::vector<i64> level_of_row_;
     TriProgram multi_, single_;

@@ -25,6 +25,7 @@ int TriSolver::analyze(const CscView &T, int kind)
     const int st = build_gather_form(T, kind, G_);
     if (st != kOk) return st;
     const double t1 = now_s();
+    kind_ = kind;
     n_ = G_.n;
     nnz_ = (i64)G_.idx.size() + n_;
     // canonical level sets (reported through rsp_tri_levels for bit-exact comparison)
@@ -82,6 +83,11 @@ static void upload_program(TriProgramHost &H, TriProgram &P)
     P.op_diag.upload(H.op_diag);
     P.ent_idx.upload(H.ent_idx);
     P.ent_val.upload(H.ent_val);
+}
+
+void TriSolver::set_values(const CscView &T)
+{
+    fill_gather_values(T, kind_, G_);
 }
 
 void TriSolver::build_program(i64 max_task_entries, TriProgram &P)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <limits>
 
+#include "parallel.hpp"
 #include "sparse.hpp"
 
 namespace rsp {
@@ -16,6 +17,7 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
     if (n >= std::numeric_limits<int32_t>::max() || T.nnz() >= std::numeric_limits<int32_t>::max()) return kBadInput;
     const bool lower_storage = (kind == 0 || kind == 1);  // L: diagonal first; U: diagonal last
     const bool by_rows = (kind == 0 || kind == 2);        // lsolve/usolve gather along ROWS of the stored factor
+    const bool pattern_only = T.x == nullptr;
     G.n = n;
     G.descending = (kind == 1 || kind == 2);
     G.diag.assign(n, 0.0);
@@ -25,7 +27,7 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
         const i64 b = T.p[j], e = T.p[j + 1];
         if (e <= b || b < 0 || e > T.nnz()) return kBadInput;  // the reference indexes the diagonal unconditionally
         const i64 dpos = lower_storage ? b : e - 1;
-        G.diag[j] = T.x[dpos];
+        if (!pattern_only) G.diag[j] = T.x[dpos];
         for (i64 p = (lower_storage ? b + 1 : b); p < (lower_storage ? e : e - 1); ++p) {
             const i64 i = T.i[p];
             // off-diagonal entries must lie strictly inside the triangle, otherwise the loops of the reference
@@ -37,7 +39,9 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
     for (i64 r = 0; r < n; ++r) G.ptr[r + 1] += G.ptr[r];
     const i64 nz = G.ptr[n];
     G.idx.resize(nz);
-    G.val.resize(nz);
+    G.val.assign(nz, 0.0);
+    G.src.clear();
+    if (pattern_only) G.src.resize(nz);
     std::vector<i64> fill(G.ptr.begin(), G.ptr.end() - 1);
     // visit source columns in the order the reference's loop visits them, so each unknown accumulates its terms
     // in the reference's order: ascending j for lsolve/utsolve, descending j for ltsolve/usolve
@@ -48,10 +52,22 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
             const i64 i = T.i[p];
             const i64 q = fill[by_rows ? i : j]++;
             G.idx[q] = (int32_t)(by_rows ? j : i);
-            G.val[q] = T.x[p];
+            if (pattern_only) G.src[q] = (int32_t)p;
+            else G.val[q] = T.x[p];
         }
     }
     return kOk;
+}
+
+void fill_gather_values(const CscView &T, int kind, GatherForm &G)
+{
+    const bool lower_storage = (kind == 0 || kind == 1);
+    for (i64 j = 0; j < G.n; ++j) G.diag[j] = T.x[lower_storage ? T.p[j] : T.p[j + 1] - 1];
+    const double *x = T.x;
+    parallel_ranges((i64)G.src.size(), 1 << 18, [&](i64 lo, i64 hi) {
+        for (i64 q = lo; q < hi; ++q) G.val[q] = x[G.src[q]];
+    });
+    std::vector<int32_t>().swap(G.src);
 }
 
 Schedule build_schedule(const GatherForm &G, i64 max_task_entries)

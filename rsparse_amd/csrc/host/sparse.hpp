@@ -93,9 +93,13 @@ struct GatherForm {
     std::vector<int32_t> idx;  // off-diagonal column of each entry
     std::vector<double> val;
     std::vector<double> diag;  // n
+    std::vector<int32_t> src;  // pattern-only build: position in T.x of each entry, until fill_gather_values()
 };
 // kind: 0 lsolve, 1 ltsolve, 2 usolve, 3 utsolve (include/rsparse_hip.h rsp_tri_kind). Returns kOk or kBadInput.
+// T.x == nullptr builds the pattern only (val and diag stay zero, src remembers where every value will come from).
 int build_gather_form(const CscView &T, int kind, GatherForm &out);
+// the values of a pattern-only gather form, from the same matrix with T.x present
+void fill_gather_values(const CscView &T, int kind, GatherForm &G);
 
 // Level schedule over "tasks".  A task is a run of consecutive unknowns (in processing order) solved
 // sequentially by one wavefront; all of its dependencies outside the run belong to tasks of lower levels.
