@@ -90,7 +90,8 @@ void rsp_tri_free(rsp_tri *h);
  * bounds-checked and every read checked against the level that produces it.
  * report[0..7] = bad indices, order violations, unknowns not written exactly once, levels, block tasks, clusters,
  *                unknowns inside clusters, kernel launches per sweep;  *max_rel_error = against sequential substitution.
- * task_blocks / cluster_slots <= 0 select the library defaults. */
+ * task_blocks <= 0 and cluster_slots == 0 select the library defaults; cluster_slots > 0 builds group-record clusters of
+ * that many LDS slots, cluster_slots < 0 dense matrix-core tasks of -cluster_slots slots (the bottom of the forest). */
 int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
                              double *max_rel_error);
 

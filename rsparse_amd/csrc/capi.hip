@@ -240,8 +240,10 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
     return guarded([&] {
         GatherForm G;
         if (int st = build_gather_form(view_of(T), kind, G)) return st;
-        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks,
-                                                   cluster_slots > 0 ? cluster_slots : kClusterSlots);
+        // cluster_slots > 0: group-record clusters of that many slots; < 0: dense tasks of -cluster_slots slots; 0: the default
+        const bool dense = cluster_slots < 0 || (cluster_slots == 0 && kDenseTasks != 0);
+        const int slots = cluster_slots > 0 ? cluster_slots : cluster_slots < 0 ? -cluster_slots : (dense ? kDenseSlots : kClusterSlots);
+        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, slots, dense);
         const ProgramReport R = check_block_program(G, P);
         report[0] = R.bad_index;
         report[1] = R.order_violations;

@@ -105,6 +105,11 @@ struct BlockedProgram {
     DeviceBuffer<ClusterHeader> clusters;
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
+    bool dense = false;  // the clusters are dense tasks (dense_kernels.hip)
+    DeviceBuffer<uint16_t> dense_slots;
+    DeviceBuffer<int32_t> dense_meta;
+    DeviceBuffer<double> dense_coef;
+    i64 dense_nodes = 0, dense_ksteps = 0;
     struct Level {
         i64 task_begin[4];  // by class (BlockProgram::level_class_ptr)
         int ntasks[4];
@@ -117,7 +122,7 @@ struct BlockedProgram {
     size_t device_bytes() const
     {
         return task_ptr.bytes() + hdr.bytes() + prologue.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
-               groups.bytes();
+               groups.bytes() + dense_slots.bytes() + dense_meta.bytes() + dense_coef.bytes();
     }
 };
 
@@ -187,6 +192,8 @@ constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 rig
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)
 constexpr i64 kLeanMode = 2;  // lean variant of solve_level: 0 = one 16-source stage, 2 = two alternating 8-source half stages
 constexpr i64 kLeanLaunchWorkgroupsSingle = 128;  // the same switch for a single right-hand side (deep-fetch gather)
+constexpr i64 kDenseTasks = 0;   // 1: the bottom of the forest runs as dense LDS tasks (dense_kernels.hip), 0: as group-record clusters
+constexpr i64 kDenseNT = 1;      // 16-column tiles per wavefront of a dense task
 constexpr i64 kSmallLaunchWaves = 2048;  // small-block tasks of a level get their own launch from this many wavefronts
 
 }  // namespace rsp

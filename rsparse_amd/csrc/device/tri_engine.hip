@@ -11,6 +11,7 @@
 #include "solve_kernels.hip"
 #include "blocked_kernels.hip"
 #include "cluster_kernels.hip"
+#include "dense_kernels.hip"
 
 namespace rsp {
 
@@ -136,8 +137,11 @@ static i64 env_or(const char *name, i64 fallback)
 // host half of build_blocked(): no device call, so two solvers can be staged on two host threads
 void TriSolver::stage_blocked()
 {
-    staged_.reset(new BlockProgram(
-        build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots))));
+    const bool dense = env_or("RSP_DENSE_TASKS", kDenseTasks) != 0;
+    // a dense task's rows must fit the LDS share of a wavefront: four wavefronts per CU, 128 bytes per slot and column tile
+    const i64 nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
+    const i64 slots = dense ? std::min<i64>(env_or("RSP_DENSE_SLOTS", kDenseSlots / nt), 1200 / nt) : env_or("RSP_CLUSTER_SLOTS", kClusterSlots);
+    staged_.reset(new BlockProgram(build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)slots, dense)));
 }
 
 void TriSolver::set_single_use()
@@ -236,8 +240,27 @@ void TriSolver::build_blocked()
     D.clusters.upload(P.clusters);
     D.cluster_ids.upload(P.cluster_ids);
     D.groups.upload(P.groups);
+    D.dense = P.dense;
+    D.dense_nodes = P.dense_nodes;
+    D.dense_ksteps = (i64)P.dense_meta.size();
+    if (P.dense) {
+        // the kernel prefetches whole quads of k-steps with clamped indices: never past these ends
+        D.dense_slots.upload(P.dense_slots);
+        D.dense_meta.upload(P.dense_meta);
+        D.dense_coef.upload(P.dense_coef);
+        auto allow = [&](const void *f, int nt) {
+            const int bytes = (D.cluster_slots + 1) * 128 * nt;
+            if (bytes <= 160 * 1024) RSP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        };
+        allow((const void *)dev::solve_dense_tasks<1, true>, 1);
+        allow((const void *)dev::solve_dense_tasks<1, false>, 1);
+        allow((const void *)dev::solve_dense_tasks<2, true>, 2);
+        allow((const void *)dev::solve_dense_tasks<2, false>, 2);
+        allow((const void *)dev::solve_dense_tasks<4, true>, 4);
+        allow((const void *)dev::solve_dense_tasks<4, false>, 4);
+    }
     RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                4 * (D.cluster_slots * 512 + 1024)));
+                                4 * (std::min(D.cluster_slots, 64) * 512 + 1024)));
     if (getenv("RSP_TIMING")) fprintf(stderr, "tri programme: build %.2fs, upload %.2fs\n", tb1 - tb0, now_s() - tb1);
 }
 
@@ -287,7 +310,21 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             recorded = true;
         }
         done += (i64)lv.nclusters * nchunks + ((i64)lv.ntasks[0] * nchunks + 7) / 8;
-        if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
+        if (lv.nclusters && P.dense) {  // dense tasks: one single-wavefront workgroup per (task, 16 * NT columns)
+            static const i64 dense_nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
+            const int nt = dense_nt >= 4 ? 4 : dense_nt >= 2 ? 2 : 1;
+            const int rb = 16 * nt;
+            const int dchunks = (int)((nrhs + rb - 1) / rb);
+            const bool dfast = fast && nrhs % rb == 0;
+            const dev::DenseArrays DA{P.clusters.get(), P.cluster_ids.get(), P.dense_slots.get(), P.dense_meta.get(), P.dense_coef.get()};
+            const i64 wgs = ((i64)lv.nclusters * dchunks + 7) / 8 * 8;
+            const size_t lds_bytes = (size_t)(P.cluster_slots + 1) * rb * 8;
+            auto kernel = nt == 4 ? (dfast ? dev::solve_dense_tasks<4, true> : dev::solve_dense_tasks<4, false>)
+                        : nt == 2 ? (dfast ? dev::solve_dense_tasks<2, true> : dev::solve_dense_tasks<2, false>)
+                                  : (dfast ? dev::solve_dense_tasks<1, true> : dev::solve_dense_tasks<1, false>);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(64), lds_bytes, stream, DA, lv.cluster_begin, lv.nclusters, dchunks, X, ld,
+                               (int)nrhs);
+        } else if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
             const int cpw = (int)std::min<i64>(std::min<i64>(nchunks, 4), cluster_cpw);
             const size_t per_wave = (size_t)P.cluster_slots * 512 + 1024;
             const i64 wgs = ((i64)lv.nclusters * ((nchunks + cpw - 1) / cpw) + 7) / 8 * 8;  // whole rounds over the 8 XCDs

@@ -180,6 +180,20 @@ struct BlockProgram {
     std::vector<int32_t> cluster_ids;
     std::vector<GroupRec> groups;
     int32_t cluster_slots = 0;       // LDS slots a wavefront needs (max n_ext + n_own over all clusters)
+    // DENSE TASKS (dense == true): the clusters are larger (hundreds of slots) and their arithmetic is not a stream of
+    // group records but a stream of matrix-core K-STEPS (v_mfma_f64_16x16x4_f64, 16 right-hand sides per n-tile).  The
+    // unknowns of a task are cut into NODES of up to 16 consecutive unknowns; a node with in-node triangle T and
+    // source coefficients Cf (sources = earlier slots of the task) is applied as ONE dense product
+    //     x_node = [ T^-1 | -T^-1 Cf ] * [ b_node ; x_sources ]
+    // so nothing inside a node is sequential.  Per k-step: 4 slot numbers (the rows of the B operand; slot
+    // n_ext + n_own is a row of zeros used as padding), 64 doubles of the A operand in lane order (lane i + 16 g holds
+    // A[i][4 k + g]) and a meta word: 0, or for the LAST k-step of a node  1 << 31 | rows << 20 | first output slot.
+    // ClusterHeader is reused: ngroups = number of k-steps, grp_off = first k-step of the task.
+    bool dense = false;
+    std::vector<uint16_t> dense_slots;
+    std::vector<int32_t> dense_meta;
+    std::vector<double> dense_coef;
+    i64 dense_nodes = 0;
     // schedule
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
     std::vector<i64> level_ptr;      // block tasks of level l
@@ -198,7 +212,8 @@ constexpr i64 kMaxBlockSources = 1024;  // longer source lists become partial su
 constexpr int kClusterSlots = 24;    // default LDS slots per cluster (12 KB per wavefront at 64 right-hand sides; measured
                                      // at C2: 24 slots beat 16, 32, 40 and 48 -- occupancy outweighs coverage)
 constexpr i64 kTaskBlocks = 1;       // default number of dependent blocks one wavefront runs back to back (measured: 1 beats 2, 3)
-BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots);
+constexpr int kDenseSlots = 288;     // default LDS slots of a dense task (36 KB per wavefront at 16 right-hand sides)
+BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots, bool dense = false);
 
 // Host-side validator of a programme (debug aid, never a solve path: it takes no user data).  Replays the programme
 // level by level on ONE synthetic right-hand side with every index bounds-checked and every read checked against the

@@ -169,7 +169,8 @@ def _program_factors():
     return [(0, L), (1, L), (0, f["L"]), (1, f["L"]), (2, f["U"]), (3, f["U"]), (0, g["L"]), (2, g["U"]), (3, g["U"])]
 
 
-@pytest.mark.parametrize("task_blocks,cluster_slots", [(0, 0), (1, 16), (4, 96), (2, 1)])
+# cluster_slots > 0: group-record clusters; < 0: dense matrix-core tasks of that many LDS slots; 0: the library default
+@pytest.mark.parametrize("task_blocks,cluster_slots", [(0, 0), (1, 16), (4, 96), (2, 1), (1, -17), (1, -40), (2, -288), (1, -1000)])
 def test_block_programme_is_valid_and_exact(task_blocks, cluster_slots):
     """Every id in range, every row read only after the level that writes it, every unknown written exactly once,
     and the replayed programme agrees with sequential substitution (rsp_tri_validate_program)."""
