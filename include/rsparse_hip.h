@@ -74,13 +74,21 @@ int rsp_tri_solve_f64(rsp_tri *h, double *X, int64_t ldx, int64_t nrhs);
 /* dX = device pointer; layout/ld as rsp_layout; runs on `stream` (a hipStream_t, NULL = default)
  * and returns without synchronising */
 int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_t nrhs, void *stream);
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): rsp_tri_solve_dev_f64 for a ROW-MAJOR device block, with the
+ * programme's scratch rows in a fixed device array of the library (32 MiB per GPU, held until the process ends) instead
+ * of a buffer allocated on demand.  Calls no hipMalloc / hipFree / allocating routine.  The handle must have solved
+ * once through rsp_tri_solve_dev_f64 or rsp_tri_solve_f64 with more than one right-hand side (that call uploads the
+ * programme); returns RSP_BAD_INPUT otherwise, and when scratch rows x nrhs exceeds 4 Mi doubles (rsp_tri_info
+ * reports the scratch rows).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race. */
+int rsp_tri_solve_dev_noalloc_f64(rsp_tri *h, double *dX, int64_t ld, int64_t nrhs, void *stream);
 /* first then second on the same device block (lsolve + ltsolve of cholsol, lsolve + usolve of lusol), row-major only:
  * wide blocks are cut into two column halves that go through both sweeps on two streams, so the nearly empty levels
  * at the top of one half's dependency tree run beside the other half's heavy levels.  Ordered after earlier work
  * on `stream`; later work on `stream` is ordered after both halves.  Not re-entrant per handle. */
 int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int64_t ld, int64_t nrhs, void *stream);
-/* info[0..7] = n, nnz, levels, tasks, kernel launches per sweep, device bytes of the factor copy,
- *              algorithmic bytes for one sweep of 1 rhs, longest task (rows) */
+/* info[0..8] = n, nnz, dependency levels of single unknowns, tasks, kernel launches per sweep, device bytes of the
+ *              programme, algorithmic bytes for one sweep of 1 rhs, unknowns in inverted chains, scratch rows */
 int rsp_tri_info(const rsp_tri *h, int64_t *info);
 /* integer schedule, for bit-exact comparison with the host oracle: level_of_row[n] */
 int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row);

@@ -63,6 +63,7 @@ def lib():
             "rsp_tri_solve_f64": (cint, [vp, vp, i64, i64]),
             "rsp_tri_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, vp]),
             "rsp_tri_solve_pair_dev_f64": (cint, [vp, vp, vp, i64, i64, vp]),
+            "rsp_tri_solve_dev_noalloc_f64": (cint, [vp, vp, i64, i64, vp]),
             "rsp_tri_info": (cint, [vp, vp]),
             "rsp_tri_levels": (cint, [vp, vp]),
             "rsp_tri_free": (None, [vp]),
@@ -382,10 +383,14 @@ class TriHandle:
     def solve_dev(self, ptr, layout, ld, nrhs, stream=None):
         _check(lib().rsp_tri_solve_dev_f64(self._h, ptr, layout, ld, nrhs, stream))
 
+    def solve_dev_noalloc(self, ptr, ld, nrhs, stream=None):
+        """Row-major device block, scratch rows in the library's fixed device array (rsp_tri_solve_dev_noalloc_f64)."""
+        _check(lib().rsp_tri_solve_dev_noalloc_f64(self._h, ptr, ld, nrhs, stream))
+
     def info(self):
-        a = np.zeros(8, np.int64)
+        a = np.zeros(9, np.int64)
         _check(lib().rsp_tri_info(self._h, a.ctypes.data))
-        keys = ("n", "nnz", "row_levels", "tasks", "launches", "device_bytes", "bytes_1rhs", "longest_task")
+        keys = ("n", "nnz", "row_levels", "tasks", "launches", "device_bytes", "bytes_1rhs", "inverted_rows", "scratch_rows")
         return dict(zip(keys, a.tolist()))
 
     def levels(self):

@@ -163,6 +163,12 @@ int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_
     });
 }
 
+int rsp_tri_solve_dev_noalloc_f64(rsp_tri *h, double *dX, int64_t ld, int64_t nrhs, void *stream)
+{
+    if (!h || !dX || nrhs < 0 || ld < nrhs) return RSP_BAD_INPUT;
+    return guarded([&] { return h->solver.solve_device_noalloc(dX, ld, nrhs, (hipStream_t)stream); });
+}
+
 int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int64_t ld, int64_t nrhs, void *stream)
 {
     if (!first || !second || !dX || nrhs < 0 || ld < nrhs || first->solver.n() != second->solver.n()) return RSP_BAD_INPUT;
@@ -186,7 +192,8 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
     info[4] = blocked ? Bp.launches : P.nlevels;
     info[5] = (int64_t)(blocked ? Bp.device_bytes() : P.device_bytes());
     info[6] = s.algorithmic_bytes(1);
-    info[7] = blocked ? Bp.inverted_rows : P.longest_task;
+    info[7] = blocked ? Bp.inverted_rows : 0;
+    info[8] = blocked ? Bp.scratch_rows : 0;
     return RSP_OK;
 }
 

@@ -155,7 +155,12 @@ class TriSolver {
     // blocked programme for a single use.  Handles that solve many times never call this.
     void set_single_use();
     bool single_use_levels() const { return single_use_levels_; }
-    void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy);
+    void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
+                    double *scratch_override = nullptr);
+    // Row-major solve that allocates nothing: the blocked programme must already be resident (one earlier solve through
+    // solve_device) and its scratch rows live in a file-scope __device__ array of kNoAllocScratchDoubles doubles.
+    // Returns kBadInput when the programme is not resident or scratch_rows * nrhs exceeds the array.
+    int solve_device_noalloc(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
 
    private:
     void build_program(i64 max_task_entries, TriProgram &P);
@@ -194,6 +199,7 @@ constexpr i64 kLeanMode = 2;  // lean variant of solve_level: 0 = one 16-source 
 constexpr i64 kLeanLaunchWorkgroupsSingle = 128;  // the same switch for a single right-hand side (deep-fetch gather)
 constexpr i64 kDenseTasks = 0;   // 1: the bottom of the forest runs as dense LDS tasks (dense_kernels.hip), 0: as group-record clusters
 constexpr i64 kDenseNT = 1;      // 16-column tiles per wavefront of a dense task
+constexpr i64 kNoAllocScratchDoubles = 4 << 20;  // 32 MiB per GPU, held until the process ends (rsp_tri_solve_dev_noalloc_f64)
 constexpr i64 kSmallLaunchWaves = 2048;  // small-block tasks of a level get their own launch from this many wavefronts
 
 }  // namespace rsp

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <exception>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <cstdlib>
 
@@ -281,11 +282,13 @@ void TriSolver::prepare_blocked(i64 total_cols)
 // Columns [col_off, col_off + nrhs) of a row-major block of `total_cols` columns whose first column is at X - col_off:
 // the scratch rows use the same column window, so two windows of one block can be in flight on two streams.
 // `after_heavy`, if given, is recorded on `stream` once 90 % of the sweep's workgroups have been launched.
-void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy)
+void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
+                           double *scratch_override)
 {
-    prepare_blocked(total_cols);
+    if (!scratch_override) prepare_blocked(total_cols);
     const BlockedProgram &P = blocked_;
-    double *const Sw = scratch_.get() ? scratch_.get() + col_off : nullptr;
+    double *const Sbase = scratch_override ? scratch_override : scratch_.get();
+    double *const Sw = Sbase ? Sbase + col_off : nullptr;
     const i64 lds = total_cols;
     const dev::BlockArrays A{P.task_ptr.get(), P.hdr.get(), P.src_idx.get(), P.coef.get(), P.prologue.get()};
     const dev::ClusterArrays C{P.clusters.get(), P.cluster_ids.get(), P.groups.get()};
@@ -421,6 +424,40 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i
         if (k) RSP_HIP(hipEventRecord(ax.done[k], sk));
     }
     for (int k = 1; k < parts; ++k) RSP_HIP(hipStreamWaitEvent(stream, ax.done[k], 0));
+}
+
+// ---- the entry point that allocates nothing (rsp_tri_solve_dev_noalloc_f64) ------------------------------------------
+// Scratch rows of the blocked programme in a file-scope device array instead of a hipMalloc'ed buffer.  In host code the
+// array's name is only a stand-in: its device address is looked up once per device with hipGetSymbolAddress and THAT
+// pointer is what the kernels receive.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race.
+// Nothing in it has to start at zero (every scratch row is written by the programme before it is read).
+static __device__ __align__(256) double g_noalloc_scratch[kNoAllocScratchDoubles];
+
+static double *noalloc_scratch_for_current_device()
+{
+    constexpr int kMaxDevices = 64;
+    static std::mutex guard;
+    static double *ptr[kMaxDevices] = {};
+    int device = 0;
+    RSP_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) throw DeviceError("device index out of range");
+    std::lock_guard<std::mutex> lock(guard);
+    if (!ptr[device]) {
+        double *p = nullptr;
+        RSP_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_noalloc_scratch)));  // this device's copy of the array
+        ptr[device] = p;
+    }
+    return ptr[device];
+}
+
+int TriSolver::solve_device_noalloc(double *X, i64 ld, i64 nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0 || n_ == 0) return kOk;
+    if (!have_blocked_) return kBadInput;  // building and uploading the programme allocates: an earlier solve must have done it
+    if (blocked_.scratch_rows > 0 && (blocked_.scratch_rows > kNoAllocScratchDoubles / nrhs)) return kBadInput;
+    double *S = noalloc_scratch_for_current_device();
+    run_window(X, ld, nrhs, 0, nrhs, stream, nullptr, S);
+    return kOk;
 }
 
 void TriSolver::run_single(double *x, hipStream_t stream)
