@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     Symb,
     TriHandle,
     validate_program,
+    validate_supernodal,
     amd,
     chol,
     cholsol,

@@ -68,6 +68,7 @@ def lib():
             "rsp_tri_levels": (cint, [vp, vp]),
             "rsp_tri_free": (None, [vp]),
             "rsp_tri_validate_program": (cint, [csc, cint, i64, cint, vp, vp]),
+            "rsp_tri_validate_supernodal": (cint, [csc, cint, vp, vp, vp]),
             "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_sqr_lu": (cint, [csc, C.c_int8, C.POINTER(vp)]),
@@ -355,6 +356,20 @@ def validate_program(t, kind, task_blocks=0, cluster_slots=0):
     err = C.c_double(0.0)
     _check(lib().rsp_tri_validate_program(C.byref(t._view()), kind, task_blocks, cluster_slots, rep.ctypes.data, C.byref(err)))
     keys = ("bad_index", "order_violations", "unwritten", "levels", "tasks", "clusters", "cluster_rows", "launches")
+    d = dict(zip(keys, rep.tolist()))
+    d["max_rel_error"] = err.value
+    return d
+
+
+def validate_supernodal(t, kind, task_slots=0, small_node=0, max_node=0, max_item_k=0):
+    """Host-only check of the supernodal programme built for `t` (rsp_tri_validate_supernodal); no GPU needed."""
+    t = _as_sprs(t)
+    opt = np.array([task_slots, small_node, max_node, max_item_k], np.int64)
+    rep = np.zeros(12, np.int64)
+    err = C.c_double(0.0)
+    _check(lib().rsp_tri_validate_supernodal(C.byref(t._view()), kind, opt.ctypes.data, rep.ctypes.data, C.byref(err)))
+    keys = ("bad_index", "order_violations", "unwritten", "levels", "items", "tasks", "task_rows", "nodes", "big_nodes",
+            "scratch_rows", "padded_flops_per_col", "coef_doubles")
     d = dict(zip(keys, rep.tolist()))
     d["max_rel_error"] = err.value
     return d

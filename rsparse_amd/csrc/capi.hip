@@ -188,6 +188,16 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
     info[2] = s.num_row_levels();
     const BlockedProgram &Bp = s.blocked_program();
     const bool blocked = Bp.nblocks > 0;  // the programme the multi-rhs path actually ran
+    if (s.uses_supernodal() && s.supernodal_program().nlevels > 0) {  // the supernodal programme ran
+        const SupernodalProgram &Sp = s.supernodal_program();
+        info[3] = Sp.nitems + Sp.ntasks;
+        info[4] = Sp.launches;
+        info[5] = (int64_t)Sp.device_bytes();
+        info[6] = s.algorithmic_bytes(1);
+        info[7] = 0;
+        info[8] = Sp.scratch_rows;
+        return RSP_OK;
+    }
     info[3] = blocked ? Bp.ntasks : P.ntasks;
     info[4] = blocked ? Bp.launches : P.nlevels;
     info[5] = (int64_t)(blocked ? Bp.device_bytes() : P.device_bytes());
@@ -263,6 +273,42 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
         for (size_t l = 0; l + 1 < P.level_ptr.size(); ++l)
             launches += (P.level_ptr[l + 1] > P.level_ptr[l]) + (P.cluster_level_ptr[l + 1] > P.cluster_level_ptr[l]);
         report[7] = launches;
+        *max_rel_error = R.max_rel_error;
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *options, int64_t *report, double *max_rel_error)
+{
+    if (!sane(T) || kind < 0 || kind > 3 || !report || !max_rel_error) return RSP_BAD_INPUT;
+    return guarded([&] {
+        GatherForm G, C;
+        if (int st = build_gather_form(view_of(T), kind, G)) return st;
+        const bool scatter = kind == RSP_LSOLVE || kind == RSP_USOLVE;
+        if (scatter)
+            if (int st = build_gather_form(view_of(T), kind ^ 1, C)) return st;
+        SnOptions opt;
+        if (options) {
+            if (options[0] > 0) opt.task_slots = (int)options[0];
+            if (options[0] < 0) opt.task_slots = 0;  // no tasks at all
+            if (options[1] > 0) opt.small_node = options[1];
+            if (options[2] > 0) opt.max_node = options[2];
+            if (options[3] > 0) opt.max_item_k = options[3];
+        }
+        const SnProgram P = build_supernodal_program(G, scatter ? &C : nullptr, scatter, opt);
+        const ProgramReport R = check_supernodal_program(G, P);
+        report[0] = R.bad_index;
+        report[1] = R.order_violations;
+        report[2] = R.unwritten;
+        report[3] = (int64_t)P.item_level_ptr.size() - 1;
+        report[4] = (int64_t)P.items.size();
+        report[5] = (int64_t)P.tasks.size();
+        report[6] = P.task_rows;
+        report[7] = P.nnodes;
+        report[8] = P.big_nodes;
+        report[9] = P.scratch_rows;
+        report[10] = P.padded_flops_per_col;
+        report[11] = (int64_t)(P.coef.size() + P.task_coef.size());
         *max_rel_error = R.max_rel_error;
         return (int)RSP_OK;
     });

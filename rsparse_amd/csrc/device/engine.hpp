@@ -106,8 +106,7 @@ struct BlockedProgram {
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
     bool dense = false;  // the clusters are dense tasks (dense_kernels.hip)
-    DeviceBuffer<uint16_t> dense_slots;
-    DeviceBuffer<int32_t> dense_meta;
+    DeviceBuffer<uint32_t> dense_steps;
     DeviceBuffer<double> dense_coef;
     i64 dense_nodes = 0, dense_ksteps = 0;
     struct Level {
@@ -122,9 +121,35 @@ struct BlockedProgram {
     size_t device_bytes() const
     {
         return task_ptr.bytes() + hdr.bytes() + prologue.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
-               groups.bytes() + dense_slots.bytes() + dense_meta.bytes() + dense_coef.bytes();
+               groups.bytes() + dense_steps.bytes() + dense_coef.bytes();
     }
 };
+
+// The supernodal multi-right-hand-side programme (host/supernodal.cpp) resident on the device.
+struct SupernodalProgram {
+    i64 nitems = 0, ntasks = 0, nlevels = 0, launches = 0, scratch_rows = 0, nnodes = 0, big_nodes = 0, task_rows = 0, padded_flops_per_col = 0;
+    int task_slots = 0;
+    DeviceBuffer<SnItem> items;
+    DeviceBuffer<int32_t> ids;
+    DeviceBuffer<double> coef;
+    DeviceBuffer<ClusterHeader> tasks;
+    DeviceBuffer<int32_t> task_ids;
+    DeviceBuffer<uint32_t> task_steps;
+    DeviceBuffer<double> task_coef;
+    struct Level {
+        i64 item_begin, task_begin;
+        int nitems, ntasks;
+        int n4, n2, n1;  // items by the number of wavefronts that share them (sorted that way inside the level)
+    };
+    std::vector<Level> levels;
+    size_t device_bytes() const
+    {
+        return items.bytes() + ids.bytes() + coef.bytes() + tasks.bytes() + task_ids.bytes() + task_steps.bytes() + task_coef.bytes();
+    }
+};
+
+// slot / node-end words of the dense-task kernel from the host programme's slots and meta arrays
+std::vector<uint32_t> pack_dense_steps(const std::vector<uint16_t> &slots, const std::vector<int32_t> &meta);
 
 // Analyse-once / solve-many engine for one triangular factor and one of the four solve kinds.
 class TriSolver {
@@ -146,6 +171,8 @@ class TriSolver {
     const TriProgram &multi_program() const { return multi_; }
     const TriProgram &single_program() const { return single_; }
     const BlockedProgram &blocked_program() const { return blocked_; }
+    const SupernodalProgram &supernodal_program() const { return sn_; }
+    bool uses_supernodal() const { return use_sn_; }
     i64 algorithmic_bytes(i64 nrhs) const { return nnz_ * 12 + (n_ + 1) * 4 + 16 * n_ * nrhs; }
     // pieces of the multi-right-hand-side path that solve_pair_device drives on two streams
     void prepare_blocked(i64 total_cols);
@@ -169,6 +196,11 @@ class TriSolver {
     void run_blocked(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
     void build_blocked();
     void run_single(double *x, hipStream_t stream);
+    // supernodal programme: staged on the host (and accepted or not) before the blocked one would be built
+    void stage_supernodal();
+    void build_supernodal();
+    void run_window_supernodal(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
+                               double *scratch_base);
 
     i64 n_ = 0, nnz_ = 0, num_row_levels_ = 0;
     int kind_ = 0;
@@ -177,10 +209,14 @@ class TriSolver {
     TriProgram multi_, single_;
     BlockedProgram blocked_;
     bool have_multi_ = false, have_single_ = false, have_blocked_ = false, single_use_levels_ = false;
+    SupernodalProgram sn_;
+    bool sn_decided_ = false, use_sn_ = false, have_sn_ = false;
+    std::unique_ptr<SnProgram> staged_sn_;
     std::unique_ptr<BlockProgram> staged_;
     std::unique_ptr<TriProgramHost> staged_single_;  // set_single_use(): the level programme, ready for upload
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
+    i64 scratch_cols_ = 0;
 };
 
 // first.solve then second.solve on one row-major device block, column halves pipelined over two streams
@@ -197,6 +233,8 @@ constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 rig
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)
 constexpr i64 kLeanMode = 2;  // lean variant of solve_level: 0 = one 16-source stage, 2 = two alternating 8-source half stages
 constexpr i64 kLeanLaunchWorkgroupsSingle = 128;  // the same switch for a single right-hand side (deep-fetch gather)
+constexpr i64 kSupernodal = 0;    // multi-right-hand-side programme: 0 blocked, 1 supernodal, 2 supernodal when it needs at most kSupernodalMaxLaunches
+constexpr i64 kSupernodalMaxLaunches = 300;
 constexpr i64 kDenseTasks = 0;   // 1: the bottom of the forest runs as dense LDS tasks (dense_kernels.hip), 0: as group-record clusters
 constexpr i64 kDenseNT = 1;      // 16-column tiles per wavefront of a dense task
 constexpr i64 kNoAllocScratchDoubles = 4 << 20;  // 32 MiB per GPU, held until the process ends (rsp_tri_solve_dev_noalloc_f64)

@@ -215,6 +215,64 @@ constexpr i64 kTaskBlocks = 1;       // default number of dependent blocks one w
 constexpr int kDenseSlots = 288;     // default LDS slots of a dense task (36 KB per wavefront at 16 right-hand sides)
 BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots, bool dense = false);
 
+// ---- supernodal.cpp -------------------------------------------------------------------------------
+// The SUPERNODAL multi-right-hand-side programme: the factor's column structure is cut into
+//   * TASKS at the bottom of the dependency forest: whole subtrees whose rows of X fit in LDS, run as dense matrix-core
+//     k-step streams (same format as the dense tasks of BlockProgram; kernel dev::solve_dense_tasks), and
+//   * NODES above them: runs of consecutive columns with nested structure (the supernodes of a Cholesky factor, relaxed
+//     for anything else).  A node with diagonal block D (w x w) and rows E below it (m of them, T_E = T[E, node]) is
+//     applied as dense products with D^-1 folded in, so nothing inside a node is sequential:
+//         gather kinds  (ltsolve, utsolve):  x_node = D^-T b_node - (T_E D^-1)^T x_E
+//         scatter kinds (lsolve, usolve):    y = b_node - (partial rows sent by earlier units);  x_node = D^-1 y;
+//                                            partial rows for E:  u_E = (T_E D^-1) y      (atomics-free fan-out)
+//     Wide nodes (w > kSnSmallNode) keep D^-1 and T_E apart (two dependent products) so that the host never forms
+//     T_E D^-1 for them.
+// Everything a node does is a list of ITEMS, each one generic product  OUT = INIT + A * IN  over rows named by ids
+// (id >= 0: row of X, id < 0: scratch row ~id; scratch row 0 is a row of zeros used as padding), at most 64 output rows
+// per item, executed by dev::sn_gemm on the matrix cores with 64 x 64 register tiles.  Items and tasks carry a level;
+// a level is one launch of each kernel.
+struct SnItem {            // 48 bytes
+    int32_t m_tiles;       // 1..4 tiles of 16 output rows
+    int32_t k_steps;       // input rows / 4 (padded with the zero row)
+    int32_t nsplit;        // wavefronts of the workgroup that share the k-steps (1, 2 or 4)
+    int32_t has_init;
+    i64 a_off;             // into coef: [k_step][row tile][64] doubles, lane i + 16 g <-> A[16 tile + i][4 k_step + g]
+    i64 out_off;           // into ids: 16 * m_tiles output rows (kNone: padding, not stored)
+    i64 in_off;            // into ids: 4 * k_steps input rows
+    i64 init_off;          // into ids: 16 * m_tiles rows the accumulators start from (kNone: 0.0)
+};
+struct SnProgram {
+    static constexpr int32_t kNone = INT32_MIN;
+    i64 n = 0;
+    bool scatter = false;
+    std::vector<SnItem> items;            // sorted by level
+    std::vector<i64> item_level_ptr;      // items of level l
+    std::vector<int32_t> ids;
+    std::vector<double> coef;
+    std::vector<ClusterHeader> tasks;     // sorted by level; ngroups = k-steps, grp_off = first k-step
+    std::vector<i64> task_level_ptr;
+    std::vector<int32_t> task_ids;        // id >= 0: row of X (loaded and, for own slots, stored); id < 0: scratch row (starts at 0.0, stored)
+    std::vector<uint16_t> task_slots;
+    std::vector<int32_t> task_meta;
+    std::vector<double> task_coef;
+    int32_t task_slots_max = 0;
+    i64 scratch_rows = 1;                 // row 0: zeros
+    // statistics
+    i64 nnodes = 0, big_nodes = 0, task_rows = 0, top_rows = 0, padded_flops_per_col = 0, partial_rows = 0;
+};
+struct SnOptions {
+    int task_slots = 288;        // LDS slots of a task
+    i64 small_node = 64;         // wider nodes are cut into wide_rows-row items with input lists of at most wide_item_k
+    i64 wide_rows = 16;
+    i64 wide_item_k = 256;
+    i64 max_node = 1024;         // widest node (the host inverts its diagonal block: O(w^3))
+    i64 max_item_k = 512;        // longer input lists are cut into partial products plus a combine item
+    double relax = 0.05;         // zeros a node may take in per real entry when it absorbs the next column
+    double dense_fill = 0.05;    // node formation inside tasks (see Builder::emit_dense_task)
+};
+// R: gather form of the solve kind; C: gather form of the dual kind (kind ^ 1; needed for the scatter kinds 0 and 2 only)
+SnProgram build_supernodal_program(const GatherForm &R, const GatherForm *C, bool scatter, const SnOptions &opt);
+
 // Host-side validator of a programme (debug aid, never a solve path: it takes no user data).  Replays the programme
 // level by level on ONE synthetic right-hand side with every index bounds-checked and every read checked against the
 // level that produces it, and compares with plain sequential substitution over the gather form.
@@ -225,5 +283,6 @@ struct ProgramReport {
     double max_rel_error = 0; // against sequential substitution
 };
 ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P);
+ProgramReport check_supernodal_program(const GatherForm &R, const SnProgram &P);
 
 }  // namespace rsp

@@ -240,6 +240,29 @@ def test_trisolve_multi_rhs_vs_oracle(kind, fac, nrhs):
         assert rel_inf(y[:, 0], 3.0 * X[:, 0] + X[:, 1]) <= 1e-9
 
 
+# the supernodal programme forced on every kind of factor (by default only factors that need few launches take it), in its
+# default shape and in a shape with small tasks, wide (unfolded) nodes and partial products with combine items
+@pytest.mark.parametrize("shape", [{}, {"RSP_SN_TASK_SLOTS": "40", "RSP_SN_SMALL_NODE": "8", "RSP_SN_MAX_ITEM_K": "32", "RSP_DENSE_NT": "2"}])
+@pytest.mark.parametrize("programme", ["1", "0"])
+@pytest.mark.parametrize("kind,fac", KINDS)
+def test_trisolve_both_programmes_vs_oracle(kind, fac, programme, shape, monkeypatch):
+    if programme == "0" and shape:
+        pytest.skip("the shape switches only affect the supernodal programme")
+    monkeypatch.setenv("RSP_SUPERNODAL", programme)
+    for k, v in shape.items():
+        monkeypatch.setenv(k, v)
+    T = factors()[fac]
+    n = T[0]
+    for nrhs in (3, 64, 200):
+        B = np.asfortranarray((2.0 * synth.splitmix64(11, n * nrhs) - 1.0).reshape(nrhs, n).T)
+        want = np.stack([orc.trisolve(kind, T, B[:, r]) for r in (0, nrhs // 2, nrhs - 1)], axis=1)
+        h = rs.TriHandle(T, KIND_ID[kind])
+        X = B.copy(order="F")
+        h.solve(X)
+        assert rel_inf(X[:, [0, nrhs // 2, nrhs - 1]], want) <= REL_X
+        assert (h.info()["launches"] > 0)
+
+
 @pytest.mark.parametrize("nrhs", [64, 96, 200, 256])
 def test_pair_solve_pipelined_halves(nrhs):
     """rsp_tri_solve_pair_dev_f64: lsolve + ltsolve with the two column halves on two streams == the oracle's loops."""

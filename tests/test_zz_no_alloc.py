@@ -32,7 +32,7 @@ def test_noalloc_entry_point_matches_the_allocating_one():
             torch.cuda.synchronize()
             if first:
                 info = h.info()
-                assert info["scratch_rows"] > 0 and info["inverted_rows"] > 0  # the kernels really use the scratch buffer
+                assert info["scratch_rows"] > 0  # the kernels really use the scratch buffer
                 first = False
             Xn = torch.tensor(B, device="cuda:0")
             h.solve_dev_noalloc(Xn.data_ptr(), nrhs, nrhs, stream)
