@@ -106,9 +106,9 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
 /* The same for the SUPERNODAL programme (dense LDS tasks at the bottom of the forest, supernode products above; debug aid,
  * host only, no reference counterpart).  options (may be NULL) = {task slots (< 0: no tasks), widest node with folded
  * inverse, widest node, longest input list of one product}; 0 selects a default.
- * report[0..11] = bad indices, order violations, unknowns not written exactly once, levels, product items, tasks,
+ * report[0..12] = bad indices, order violations, unknowns not written exactly once, levels, product items, tasks,
  *                 unknowns inside tasks, nodes, wide nodes, scratch rows, padded flops per right-hand side,
- *                 coefficient doubles. */
+ *                 coefficient doubles, task steps. */
 int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *options, int64_t *report, double *max_rel_error);
 
 /* Host-only self-test of the threaded helpers the analyses use (host/parallel.hpp; debug aid, no reference counterpart,

@@ -365,11 +365,11 @@ def validate_supernodal(t, kind, task_slots=0, small_node=0, max_node=0, max_ite
     """Host-only check of the supernodal programme built for `t` (rsp_tri_validate_supernodal); no GPU needed."""
     t = _as_sprs(t)
     opt = np.array([task_slots, small_node, max_node, max_item_k], np.int64)
-    rep = np.zeros(12, np.int64)
+    rep = np.zeros(13, np.int64)
     err = C.c_double(0.0)
     _check(lib().rsp_tri_validate_supernodal(C.byref(t._view()), kind, opt.ctypes.data, rep.ctypes.data, C.byref(err)))
     keys = ("bad_index", "order_violations", "unwritten", "levels", "items", "tasks", "task_rows", "nodes", "big_nodes",
-            "scratch_rows", "padded_flops_per_col", "coef_doubles")
+            "scratch_rows", "padded_flops_per_col", "coef_doubles", "task_steps")
     d = dict(zip(keys, rep.tolist()))
     d["max_rel_error"] = err.value
     return d

@@ -289,7 +289,7 @@ int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *o
             if (int st = build_gather_form(view_of(T), kind ^ 1, C)) return st;
         SnOptions opt;
         if (options) {
-            if (options[0] > 0) opt.task_slots = (int)options[0];
+            if (options[0] > 0) opt.task_slots = (int)std::min<int64_t>(options[0], 319);
             if (options[0] < 0) opt.task_slots = 0;  // no tasks at all
             if (options[1] > 0) opt.small_node = options[1];
             if (options[2] > 0) opt.max_node = options[2];
@@ -308,7 +308,8 @@ int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *o
         report[8] = P.big_nodes;
         report[9] = P.scratch_rows;
         report[10] = P.padded_flops_per_col;
-        report[11] = (int64_t)(P.coef.size() + P.task_coef.size());
+        report[11] = (int64_t)(P.coef.size() + 2 * P.task_recs.size());
+        report[12] = (int64_t)P.task_recs.size() / 4;
         *max_rel_error = R.max_rel_error;
         return (int)RSP_OK;
     });

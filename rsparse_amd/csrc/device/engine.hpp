@@ -134,8 +134,7 @@ struct SupernodalProgram {
     DeviceBuffer<double> coef;
     DeviceBuffer<ClusterHeader> tasks;
     DeviceBuffer<int32_t> task_ids;
-    DeviceBuffer<uint32_t> task_steps;
-    DeviceBuffer<double> task_coef;
+    DeviceBuffer<SnTaskRec> task_recs;
     struct Level {
         i64 item_begin, task_begin;
         int nitems, ntasks;
@@ -144,7 +143,7 @@ struct SupernodalProgram {
     std::vector<Level> levels;
     size_t device_bytes() const
     {
-        return items.bytes() + ids.bytes() + coef.bytes() + tasks.bytes() + task_ids.bytes() + task_steps.bytes() + task_coef.bytes();
+        return items.bytes() + ids.bytes() + coef.bytes() + tasks.bytes() + task_ids.bytes() + task_recs.bytes();
     }
 };
 

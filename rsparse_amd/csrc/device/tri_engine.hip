@@ -14,6 +14,7 @@
 #include "cluster_kernels.hip"
 #include "dense_kernels.hip"
 #include "sn_kernels.hip"
+#include "task_kernels.hip"
 
 namespace rsp {
 
@@ -178,7 +179,7 @@ void TriSolver::stage_supernodal()
     const double t0 = now_s();
     const bool scatter = kind_ == 0 || kind_ == 2;
     SnOptions opt;
-    opt.task_slots = (int)env_or("RSP_SN_TASK_SLOTS", opt.task_slots);
+    opt.task_slots = (int)std::min<i64>(env_or("RSP_SN_TASK_SLOTS", opt.task_slots), 319);  // the task kernel keeps one id per 8 slots in 40 registers
     opt.small_node = env_or("RSP_SN_SMALL_NODE", opt.small_node);
     opt.max_node = env_or("RSP_SN_MAX_NODE", opt.max_node);
     opt.max_item_k = env_or("RSP_SN_MAX_ITEM_K", opt.max_item_k);
@@ -230,19 +231,11 @@ void TriSolver::build_supernodal()
     D.coef.upload(P.coef);
     D.tasks.upload(P.tasks);
     D.task_ids.upload(P.task_ids);
-    D.task_steps.upload(pack_dense_steps(P.task_slots, P.task_meta));
-    P.task_coef.resize(P.task_coef.size() + 64, 0.0);
-    D.task_coef.upload(P.task_coef);
-    auto allow = [&](const void *f, int nt) {
-        const int bytes = (D.task_slots + 1) * 128 * nt;
-        if (bytes <= 160 * 1024) RSP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    };
-    allow((const void *)dev::solve_dense_tasks<1, true>, 1);
-    allow((const void *)dev::solve_dense_tasks<1, false>, 1);
-    allow((const void *)dev::solve_dense_tasks<2, true>, 2);
-    allow((const void *)dev::solve_dense_tasks<2, false>, 2);
-    allow((const void *)dev::solve_dense_tasks<4, true>, 4);
-    allow((const void *)dev::solve_dense_tasks<4, false>, 4);
+    D.task_recs.upload(P.task_recs);
+    const int lds_bytes = (D.task_slots + 1) * 128;
+    if (lds_bytes > 64 * 1024) throw DeviceError("tasks do not fit in LDS");
+    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_sparse_tasks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_sparse_tasks<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
 }
 
 void TriSolver::run_window_supernodal(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
@@ -253,18 +246,12 @@ void TriSolver::run_window_supernodal(double *X, i64 ld, i64 nrhs, i64 col_off, 
     const i64 lds = total_cols;
     const int nchunks = (int)((nrhs + 63) / 64);
     const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && lds % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Sw % 16) == 0;
-    static const i64 dense_nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
-    const int nt = dense_nt >= 4 ? 4 : dense_nt >= 2 ? 2 : 1;
-    const int rb = 16 * nt;
-    const int dchunks = (int)((nrhs + rb - 1) / rb);
-    const bool dfast = fast && nrhs % rb == 0;
-    const dev::DenseArrays DA{P.tasks.get(), P.task_ids.get(), P.task_steps.get(), P.task_coef.get()};
+    const int dchunks = (int)((nrhs + 15) / 16);
+    const bool dfast = fast && nrhs % 16 == 0;
+    const dev::TaskArrays DA{P.tasks.get(), P.task_ids.get(), P.task_recs.get()};
     const dev::SnArrays SA{P.items.get(), P.ids.get(), P.coef.get()};
-    const size_t lds_bytes = (size_t)(P.task_slots + 1) * rb * 8;
-    if (lds_bytes > 160 * 1024) throw DeviceError("dense tasks do not fit in LDS");
-    auto task_kernel = nt == 4 ? (dfast ? dev::solve_dense_tasks<4, true> : dev::solve_dense_tasks<4, false>)
-                     : nt == 2 ? (dfast ? dev::solve_dense_tasks<2, true> : dev::solve_dense_tasks<2, false>)
-                               : (dfast ? dev::solve_dense_tasks<1, true> : dev::solve_dense_tasks<1, false>);
+    const size_t lds_bytes = (size_t)(P.task_slots + 1) * 128;
+    auto task_kernel = dfast ? dev::solve_sparse_tasks<true> : dev::solve_sparse_tasks<false>;
     auto item_kernel = fast ? dev::sn_gemm<true> : dev::sn_gemm<false>;
     i64 total = 0, done = 0;
     if (after_heavy)

@@ -217,8 +217,9 @@ BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int c
 
 // ---- supernodal.cpp -------------------------------------------------------------------------------
 // The SUPERNODAL multi-right-hand-side programme: the factor's column structure is cut into
-//   * TASKS at the bottom of the dependency forest: whole subtrees whose rows of X fit in LDS, run as dense matrix-core
-//     k-step streams (same format as the dense tasks of BlockProgram; kernel dev::solve_dense_tasks), and
+//   * TASKS at the bottom of the dependency forest: whole subtrees whose rows of X fit in LDS.  The bottom is very
+//     sparse (a handful of entries per unknown), so a task is a stream of scalar multiply-subtract records, level by
+//     level, four unknowns of a level at a time (kernel dev::solve_sparse_tasks), and
 //   * NODES above them: runs of consecutive columns with nested structure (the supernodes of a Cholesky factor, relaxed
 //     for anything else).  A node with diagonal block D (w x w) and rows E below it (m of them, T_E = T[E, node]) is
 //     applied as dense products with D^-1 folded in, so nothing inside a node is sequential:
@@ -241,6 +242,15 @@ struct SnItem {            // 48 bytes
     i64 in_off;            // into ids: 4 * k_steps input rows
     i64 init_off;          // into ids: 16 * m_tiles rows the accumulators start from (kNone: 0.0)
 };
+// One (step, lane group) of a task's arithmetic: the four lane groups of a wavefront (16 right-hand sides each) work on
+// four different unknowns of the same dependency level at once.
+struct SnTaskRec {      // 16 bytes
+    double coef;        // kEntry: T[row, source]; kEnd: 1 / diagonal (1.0 for a partial row)
+    uint32_t slot;      // kEntry: slot of the source; kBegin / kEnd: slot of the unknown itself (kBegin of a partial row: the zero slot)
+    uint32_t op;        // (all four dwords are used by the kernel: a dead dword would be reused as a temporary while the load is in flight)
+    static constexpr uint32_t kNothing = 0, kEntry = 1 /* acc -= coef * x[slot] */, kBegin = 2 /* acc = x[slot] */,
+                              kEnd = 3 /* x[slot] = acc * coef */;
+};
 struct SnProgram {
     static constexpr int32_t kNone = INT32_MIN;
     i64 n = 0;
@@ -249,27 +259,26 @@ struct SnProgram {
     std::vector<i64> item_level_ptr;      // items of level l
     std::vector<int32_t> ids;
     std::vector<double> coef;
-    std::vector<ClusterHeader> tasks;     // sorted by level; ngroups = k-steps, grp_off = first k-step
+    std::vector<ClusterHeader> tasks;     // sorted by level; ngroups = steps (a multiple of kTaskWindow), grp_off = first step
     std::vector<i64> task_level_ptr;
     std::vector<int32_t> task_ids;        // id >= 0: row of X (loaded and, for own slots, stored); id < 0: scratch row (starts at 0.0, stored)
-    std::vector<uint16_t> task_slots;
-    std::vector<int32_t> task_meta;
-    std::vector<double> task_coef;
+    std::vector<SnTaskRec> task_recs;     // 4 per step (one per lane group); a task's steps: [grp_off, grp_off + ngroups)
     int32_t task_slots_max = 0;
     i64 scratch_rows = 1;                 // row 0: zeros
     // statistics
     i64 nnodes = 0, big_nodes = 0, task_rows = 0, top_rows = 0, padded_flops_per_col = 0, partial_rows = 0;
 };
 struct SnOptions {
-    int task_slots = 288;        // LDS slots of a task
+    int task_slots = 160;        // LDS slots of a task (at most 319)
     i64 small_node = 64;         // wider nodes are cut into wide_rows-row items with input lists of at most wide_item_k
     i64 wide_rows = 16;
     i64 wide_item_k = 256;
     i64 max_node = 1024;         // widest node (the host inverts its diagonal block: O(w^3))
     i64 max_item_k = 512;        // longer input lists are cut into partial products plus a combine item
     double relax = 0.05;         // zeros a node may take in per real entry when it absorbs the next column
-    double dense_fill = 0.05;    // node formation inside tasks (see Builder::emit_dense_task)
 };
+constexpr int kTaskWindow = 4;   // steps a wavefront processes together (their LDS reads are issued before any of them is used)
+constexpr int kTaskDepth = 6;    // windows of records in flight; a task's steps are padded to whole rings (kTaskWindow * kTaskDepth)
 // R: gather form of the solve kind; C: gather form of the dual kind (kind ^ 1; needed for the scatter kinds 0 and 2 only)
 SnProgram build_supernodal_program(const GatherForm &R, const GatherForm *C, bool scatter, const SnOptions &opt);
 

@@ -344,7 +344,7 @@ class SnBuilder {
         const int32_t n_ext = scatter_ ? 0 : (int32_t)m;
         const int32_t n_total = (int32_t)(n_own + m);  // slots in use
         const int32_t zero_slot = n_total;
-        ClusterHeader h{n_ext, (int32_t)(n_total - n_ext), 0, 0, (i64)P_.task_ids.size(), (i64)P_.task_meta.size()};
+        ClusterHeader h{n_ext, (int32_t)(n_total - n_ext), 0, 0, (i64)P_.task_ids.size(), (i64)P_.task_recs.size() / 4};
         auto pos_at = [&](i64 k) { return scatter_ ? lo + k : hi - k; };
         if (!scatter_)
             for (i64 k = 0; k < m; ++k) {
@@ -360,98 +360,24 @@ class SnBuilder {
                 slot_[epool_[u.e_off + k]] = (int32_t)(n_own + k);
                 P_.task_ids.push_back(~(int32_t)(u.sid + k));
             }
-        std::vector<int32_t> uni;
-        std::vector<double> T, Ti, Cf, As;
-        auto push_steps = [&](int w, int ns, int32_t first_out, bool with_own) {
-            // A = [ Ti | As ]: own k-steps (the node's right-hand sides) then source k-steps
-            const int own_steps = with_own ? (w + 3) / 4 : 0, src_steps = (ns + 3) / 4, steps = own_steps + src_steps;
-            for (int q = 0; q < steps; ++q) {
-                const bool own = q < own_steps;
-                const int base = own ? 4 * q : 4 * (q - own_steps);
-                for (int g = 0; g < 4; ++g) {
-                    const int e = base + g;
-                    int32_t sl = zero_slot;
-                    if (own ? e < w : e < ns) sl = own ? first_out + e : uni[e];
-                    P_.task_slots.push_back((uint16_t)sl);
-                }
-                const size_t at = P_.task_coef.size();
-                P_.task_coef.resize(at + 64, 0.0);
-                for (int g = 0; g < 4; ++g) {
-                    const int e = base + g;
-                    if (!(own ? e < w : e < ns)) continue;
-                    for (int a = 0; a < w; ++a) P_.task_coef[at + (size_t)g * 16 + a] = own ? Ti[(size_t)a * w + e] : As[(size_t)a * ns + e];
-                }
-                P_.task_meta.push_back(q + 1 == steps ? (int32_t)(0x80000000u | ((uint32_t)w << 20) | (uint32_t)first_out) : 0);
+        // ---- rows of the task: its own unknowns (x = (b - sum T x_src) / d) and, for the scatter kinds, the partial rows
+        //      u_q = sum_c T[q, c] x_c over the task's columns; each with the level of its latest source inside the task ----
+        struct Row { int32_t slot, level; i64 e0, e1; double scale; bool partial; };
+        std::vector<Row> rows;
+        std::vector<std::pair<int32_t, double>> ent;  // (source slot, coefficient as subtracted)
+        std::vector<int32_t> slot_level((size_t)n_total + 1, -1);  // level at which a slot's value is final (-1: on arrival)
+        for (i64 k = 0; k < n_own; ++k) {
+            const i64 r = row_of(pos_at(k));
+            Row row{n_ext + (int32_t)k, 0, (i64)ent.size(), 0, 1.0 / R_.diag[r], false};
+            for (i64 e = R_.ptr[r]; e < R_.ptr[r + 1]; ++e) {
+                const int32_t sl = slot_[pos_of(R_.idx[e])];
+                ent.emplace_back(sl, R_.val[e]);
+                row.level = std::max(row.level, slot_level[sl] + 1);
             }
-            P_.padded_flops_per_col += 2 * 64 * steps;
-        };
-        // ---- the task's own unknowns: nodes of up to 16, x_node = [T^-1 | -T^-1 Cf] [b_node ; x_sources] ----
-        for (i64 k0 = 0; k0 < n_own;) {
-            const int32_t first_own = n_ext + (int32_t)k0;
-            ++stamp_id_;
-            uni.clear();
-            i64 entries = 0, k1 = k0;
-            while (k1 < n_own && k1 - k0 < 16) {
-                const i64 r = row_of(pos_at(k1));
-                i64 add_uni = 0, add_ent = 0;
-                for (i64 e = R_.ptr[r]; e < R_.ptr[r + 1]; ++e) {
-                    const i64 q = pos_of(R_.idx[e]);
-                    if (slot_[q] >= first_own && q >= lo && q <= hi) continue;  // inside the node
-                    ++add_ent;
-                    if (stamp_[q] != stamp_id_) ++add_uni;
-                }
-                const i64 rows = k1 - k0 + 1, nu = (i64)uni.size() + add_uni;
-                if (k1 > k0 && nu > 0 && (double)(entries + add_ent) < opt_.dense_fill * (double)(rows * nu)) break;
-                for (i64 e = R_.ptr[r]; e < R_.ptr[r + 1]; ++e) {
-                    const i64 q = pos_of(R_.idx[e]);
-                    if (slot_[q] >= first_own && q >= lo && q <= hi) continue;
-                    if (stamp_[q] != stamp_id_) {
-                        stamp_[q] = stamp_id_;
-                        uni.push_back(slot_[q]);
-                    }
-                }
-                entries += add_ent;
-                ++k1;
-            }
-            const int w = (int)(k1 - k0);
-            std::sort(uni.begin(), uni.end());
-            const int ns = (int)uni.size();
-            T.assign((size_t)w * w, 0.0);
-            Cf.assign((size_t)w * std::max(ns, 1), 0.0);
-            for (int a = 0; a < w; ++a) {
-                const i64 r = row_of(pos_at(k0 + a));
-                T[(size_t)a * w + a] = R_.diag[r];
-                for (i64 e = R_.ptr[r]; e < R_.ptr[r + 1]; ++e) {
-                    const i64 q = pos_of(R_.idx[e]);
-                    const int32_t sl = slot_[q];
-                    if (sl >= first_own && q >= lo && q <= hi) {
-                        T[(size_t)a * w + (sl - first_own)] += R_.val[e];
-                    } else {
-                        const int x = (int)(std::lower_bound(uni.begin(), uni.end(), sl) - uni.begin());
-                        Cf[(size_t)a * ns + x] += R_.val[e];
-                    }
-                }
-            }
-            Ti.assign((size_t)w * w, 0.0);
-            for (int cc = 0; cc < w; ++cc) {
-                Ti[(size_t)cc * w + cc] = 1.0 / T[(size_t)cc * w + cc];
-                for (int a = cc + 1; a < w; ++a) {
-                    double sum = 0.0;
-                    for (int t = cc; t < a; ++t) sum += T[(size_t)a * w + t] * Ti[(size_t)t * w + cc];
-                    Ti[(size_t)a * w + cc] = -sum / T[(size_t)a * w + a];
-                }
-            }
-            As.assign((size_t)w * std::max(ns, 1), 0.0);
-            for (int a = 0; a < w; ++a)
-                for (int t = 0; t <= a; ++t) {
-                    const double ti = Ti[(size_t)a * w + t];
-                    if (ti == 0.0) continue;
-                    for (int x = 0; x < ns; ++x) As[(size_t)a * ns + x] -= ti * Cf[(size_t)t * ns + x];
-                }
-            push_steps(w, ns, first_own, true);
-            k0 = k1;
+            row.e1 = (i64)ent.size();
+            slot_level[row.slot] = row.level;
+            rows.push_back(row);
         }
-        // ---- scatter kinds: the partial rows  u_q = sum_c T[q, c] x_c  over the task's columns c, 16 rows of E at a time ----
         if (scatter_ && m > 0) {
             struct Tr { int32_t k, sl; double v; };
             std::vector<Tr> tr;
@@ -462,27 +388,50 @@ class SnBuilder {
                     if (q > hi) tr.push_back(Tr{slot_[q] - (int32_t)n_own, slot_[p], S_.val[e]});
                 }
             }
-            std::sort(tr.begin(), tr.end(), [](const Tr &x, const Tr &y) { return x.k != y.k ? x.k < y.k : x.sl < y.sl; });
-            size_t at = 0;
-            for (i64 g0 = 0; g0 < m; g0 += 16) {
-                const int w = (int)std::min<i64>(16, m - g0);
-                size_t end = at;
-                uni.clear();
-                while (end < tr.size() && tr[end].k < g0 + 16) uni.push_back(tr[end++].sl);
-                std::sort(uni.begin(), uni.end());
-                uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-                const int ns = (int)uni.size();
-                As.assign((size_t)w * std::max(ns, 1), 0.0);
-                for (size_t x = at; x < end; ++x) {
-                    const int e = (int)(std::lower_bound(uni.begin(), uni.end(), tr[x].sl) - uni.begin());
-                    As[(size_t)(tr[x].k - g0) * ns + e] += tr[x].v;
+            std::stable_sort(tr.begin(), tr.end(), [](const Tr &x, const Tr &y) { return x.k < y.k; });
+            for (size_t at = 0; at < tr.size();) {
+                Row row{(int32_t)n_own + tr[at].k, 0, (i64)ent.size(), 0, 1.0, true};
+                const int32_t k = tr[at].k;
+                for (; at < tr.size() && tr[at].k == k; ++at) {
+                    ent.emplace_back(tr[at].sl, -tr[at].v);  // acc -= (-T) x: the partial row is +sum T x
+                    row.level = std::max(row.level, slot_level[tr[at].sl] + 1);
                 }
-                Ti.clear();
-                push_steps(w, ns, (int32_t)(n_own + g0), false);
-                at = end;
+                row.e1 = (i64)ent.size();
+                rows.push_back(row);
             }
         }
-        h.ngroups = (int32_t)((i64)P_.task_meta.size() - h.grp_off);
+        // ---- level by level: the level's rows are dealt to the four lane groups (longest first, to the least loaded
+        //      group), a group runs its rows one after the other, and the level is padded to whole windows ----
+        int32_t nlev = 0;
+        for (const Row &row : rows) nlev = std::max(nlev, row.level + 1);
+        std::vector<std::vector<int32_t>> by_level((size_t)nlev);
+        for (size_t x = 0; x < rows.size(); ++x) by_level[rows[x].level].push_back((int32_t)x);
+        const SnTaskRec nothing{0.0, (uint32_t)zero_slot, SnTaskRec::kNothing};
+        std::vector<SnTaskRec> seq[4];
+        for (int32_t l = 0; l < nlev; ++l) {
+            std::vector<int32_t> &rl = by_level[l];
+            std::stable_sort(rl.begin(), rl.end(), [&](int32_t x, int32_t y) { return rows[x].e1 - rows[x].e0 > rows[y].e1 - rows[y].e0; });
+            for (int g = 0; g < 4; ++g) seq[g].clear();
+            for (int32_t x : rl) {
+                int g = 0;
+                for (int q = 1; q < 4; ++q)
+                    if (seq[q].size() < seq[g].size()) g = q;
+                const Row &row = rows[x];
+                seq[g].push_back(SnTaskRec{0.0, (uint32_t)(row.partial ? zero_slot : row.slot), SnTaskRec::kBegin});
+                for (i64 e = row.e0; e < row.e1; ++e) seq[g].push_back(SnTaskRec{ent[e].second, (uint32_t)ent[e].first, SnTaskRec::kEntry});
+                seq[g].push_back(SnTaskRec{row.scale, (uint32_t)row.slot, SnTaskRec::kEnd});
+            }
+            size_t len = 0;
+            for (int g = 0; g < 4; ++g) len = std::max(len, seq[g].size());
+            len = (len + kTaskWindow - 1) / kTaskWindow * kTaskWindow;
+            for (size_t st = 0; st < len; ++st)
+                for (int g = 0; g < 4; ++g) P_.task_recs.push_back(st < seq[g].size() ? seq[g][st] : nothing);
+            P_.padded_flops_per_col += 2 * 4 * (i64)len;
+        }
+        // whole rings of windows: the kernel's loop body is unconditional (exact vmcnt bookkeeping needs straight-line code)
+        while (((i64)P_.task_recs.size() / 4 - h.grp_off) % (kTaskWindow * kTaskDepth))
+            for (int g = 0; g < 4; ++g) P_.task_recs.push_back(nothing);
+        h.ngroups = (int32_t)((i64)P_.task_recs.size() / 4 - h.grp_off);
         tasks_.push_back(h);
         task_level_.push_back((int32_t)level);
         P_.task_slots_max = std::max<int32_t>(P_.task_slots_max, n_total);
@@ -751,13 +700,11 @@ ProgramReport check_supernodal_program(const GatherForm &G, const SnProgram &P)
             const i64 unit = -10 - c;
             const i64 ns = h.n_ext + h.n_own;
             if (ns > P.task_slots_max || ns + 1 > 65535 || h.ids_off < 0 || h.ids_off + ns > (i64)P.task_ids.size() || h.grp_off < 0 ||
-                h.grp_off + h.ngroups > (i64)P.task_meta.size() || h.ngroups < 1 || P.task_slots.size() != 4 * P.task_meta.size() ||
-                P.task_coef.size() != 64 * P.task_meta.size()) {
+                (h.grp_off + h.ngroups) * 4 > (i64)P.task_recs.size() || h.ngroups < 0 || h.ngroups % kTaskWindow) {
                 ++R.bad_index;
                 continue;
             }
             std::vector<double> lds(ns + 1, 0.0);
-            std::vector<char> final_slot(ns + 1, 0);
             bool ok = true;
             for (i64 s = 0; s < ns; ++s) {
                 const int32_t id = P.task_ids[h.ids_off + s];
@@ -766,39 +713,40 @@ ProgramReport check_supernodal_program(const GatherForm &G, const SnProgram &P)
                     note_read(id, l, unit);
                     lds[s] = x[id];
                 }
-                final_slot[s] = s < h.n_ext;
             }
             if (!ok) continue;
-            final_slot[ns] = 1;
-            double acc[16];
-            std::fill(acc, acc + 16, 0.0);
-            i64 next_out = h.n_ext;
-            for (i64 qs = h.grp_off; qs < h.grp_off + h.ngroups;) {
-                i64 qe = qs;
-                while (qe < h.grp_off + h.ngroups && P.task_meta[qe] >= 0) ++qe;
-                if (qe == h.grp_off + h.ngroups) { ++R.bad_index; break; }
-                const int32_t m = P.task_meta[qe];
-                const i64 w = (m >> 20) & 31, out = m & 0xFFFFF;
-                if (w < 1 || w > 16 || out != next_out || out + w > ns) { ++R.bad_index; break; }
-                for (i64 q = qs; q <= qe; ++q)
-                    for (int g = 0; g < 4; ++g) {
-                        const i64 sl = P.task_slots[4 * q + g];
-                        if (sl > ns) { ++R.bad_index; continue; }
-                        bool used = false;
-                        for (int a = 0; a < 16; ++a) {
-                            const double cf = P.task_coef[64 * q + 16 * g + a];
-                            used = used || cf != 0.0;
-                            if (a >= w && cf != 0.0) ++R.bad_index;
-                            acc[a] += cf * lds[sl];
-                        }
-                        if (used && !final_slot[sl] && !(sl >= out && sl < out + w)) ++R.order_violations;
+            // replay of dev::solve_sparse_tasks: per window, every group reads its four operands, then runs its four steps.
+            // written[s]: window in which slot s received its final value (a read in the same or an earlier window than the
+            // write it depends on would see the old value on the device)
+            std::vector<i64> written(ns + 1, -1);
+            std::vector<char> done(ns + 1, 0);
+            double acc[4] = {0, 0, 0, 0};
+            for (i64 w0 = 0; w0 < h.ngroups; w0 += kTaskWindow) {
+                double t[4][kTaskWindow];
+                for (int g = 0; g < 4; ++g)
+                    for (int u = 0; u < kTaskWindow; ++u) {
+                        const SnTaskRec &rec = P.task_recs[(h.grp_off + w0 + u) * 4 + g];
+                        if (rec.slot > ns || rec.op > SnTaskRec::kEnd) { ++R.bad_index; t[g][u] = 0.0; continue; }
+                        t[g][u] = lds[rec.slot];
+                        if (rec.op == SnTaskRec::kEntry && (i64)rec.slot >= h.n_ext && !(done[rec.slot] && written[rec.slot] < w0)) ++R.order_violations;
+                        if (rec.op == SnTaskRec::kBegin && rec.slot < ns && done[rec.slot]) ++R.order_violations;
                     }
-                for (i64 a = 0; a < w; ++a) { lds[out + a] = acc[a]; final_slot[out + a] = 1; }
-                next_out = out + w;
-                std::fill(acc, acc + 16, 0.0);
-                qs = qe + 1;
+                for (int u = 0; u < kTaskWindow; ++u)
+                    for (int g = 0; g < 4; ++g) {
+                        const SnTaskRec &rec = P.task_recs[(h.grp_off + w0 + u) * 4 + g];
+                        if (rec.slot > ns) continue;
+                        if (rec.op == SnTaskRec::kBegin) acc[g] = t[g][u];
+                        else if (rec.op == SnTaskRec::kEntry) acc[g] -= rec.coef * t[g][u];
+                        else if (rec.op == SnTaskRec::kEnd) {
+                            if ((i64)rec.slot < h.n_ext || (i64)rec.slot >= ns || done[rec.slot]) { ++R.bad_index; continue; }
+                            lds[rec.slot] = acc[g] * rec.coef;
+                            done[rec.slot] = 1;
+                            written[rec.slot] = w0;
+                        }
+                    }
             }
-            if (next_out != ns) ++R.unwritten;
+            for (i64 s = h.n_ext; s < ns; ++s)
+                if (!done[s]) ++R.unwritten;
             for (i64 s = h.n_ext; s < ns; ++s) {
                 const int32_t id = P.task_ids[h.ids_off + s];
                 note_write(id, l, unit);

@@ -243,12 +243,14 @@ def test_trisolve_multi_rhs_vs_oracle(kind, fac, nrhs):
 # the supernodal programme forced on every kind of factor (by default only factors that need few launches take it), in its
 # default shape and in a shape with small tasks, wide (unfolded) nodes and partial products with combine items
 @pytest.mark.parametrize("shape", [{}, {"RSP_SN_TASK_SLOTS": "40", "RSP_SN_SMALL_NODE": "8", "RSP_SN_MAX_ITEM_K": "32", "RSP_DENSE_NT": "2"}])
-@pytest.mark.parametrize("programme", ["1", "0"])
+@pytest.mark.parametrize("programme", ["1", "0", "dense"])
 @pytest.mark.parametrize("kind,fac", KINDS)
 def test_trisolve_both_programmes_vs_oracle(kind, fac, programme, shape, monkeypatch):
-    if programme == "0" and shape:
+    if programme != "1" and shape:
         pytest.skip("the shape switches only affect the supernodal programme")
-    monkeypatch.setenv("RSP_SUPERNODAL", programme)
+    monkeypatch.setenv("RSP_SUPERNODAL", "1" if programme == "1" else "0")
+    if programme == "dense":  # the blocked programme with dense matrix-core tasks in place of its group-record clusters
+        monkeypatch.setenv("RSP_DENSE_TASKS", "1")
     for k, v in shape.items():
         monkeypatch.setenv(k, v)
     T = factors()[fac]
