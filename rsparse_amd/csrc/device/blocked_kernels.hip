@@ -31,19 +31,36 @@ struct BlockArrays {
     const int32_t *prologue;     // BlockProgram::kPrologueWords int32 per record (host/sparse.hpp)
 };
 
-// A prologue record spread over the wavefront: lane l holds words l and 64 + l.  Header, destination / initial-value ids
-// and the ids of the first stage(s) arrive in ONE round trip; after it the wavefront goes straight to the rows of X.
+// A prologue record spread over the wavefront (host/sparse.hpp: lines of 64 words): lane l holds word l of line 0 (header,
+// destination / initial-value ids, a vector block's first source ids) and word l of the id lines (matrix-core blocks: the
+// ids of all sources of this wavefront).  Everything arrives in ONE round trip; after it the wavefront goes straight to X.
 struct Prologue {
-    int32_t r0, r1;
+    int32_t r0, ids0, ids1;
 };
 
-template <bool SECOND>
-__device__ __forceinline__ Prologue load_prologue(const BlockArrays &B, int64_t rec, int lane)
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+
+// LINES: lines of the record (2 or 3, interleaved: lane l owns words l * LINES ...); NL: id lines wanted (0: a vector block)
+template <int LINES, int NL>
+__device__ __forceinline__ Prologue load_prologue(const BlockArrays &B, int64_t line, int lane)
 {
-    const int32_t *p = B.prologue + rec * BlockProgram::kPrologueWords;
+    const int32_t *p = B.prologue + line * BlockProgram::kLineWords + lane * LINES;
     Prologue R;
-    R.r0 = p[lane];
-    R.r1 = SECOND ? p[64 + lane] : 0;
+    if (NL == 0) {
+        R.r0 = p[0];
+        R.ids0 = R.ids1 = 0;
+    } else if (LINES == 2) {
+        const i32x2 v = *reinterpret_cast<const i32x2 *>(p);  // ONE load: the ids must not become a second round trip
+        R.r0 = v.x;
+        R.ids0 = v.y;
+        R.ids1 = 0;
+    } else {
+        const i32x3 v = *reinterpret_cast<const i32x3 *>(p);
+        R.r0 = v.x;
+        R.ids0 = v.y;
+        R.ids1 = v.z;
+    }
     return R;
 }
 
@@ -140,73 +157,106 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const Prologu
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// ---- matrix-core path: 16 unknowns x 64 right-hand sides ----------------------------------------------------
+// ---- matrix-core path: 16 unknowns x 16 NT right-hand sides ------------------------------------------------
 // acc lives in the C/D layout of v_mfma_f64_16x16x4_f64: lane (g = lane >> 4, j = lane & 15), register s <-> unknown
-// 4*s + g, columns cw + 4*j + nt for the 4 tiles nt (every lane owns 4 CONSECUTIVE doubles of a row: 32-byte accesses).
-// One K-step consumes 4 sources: A = coefficients (lane (g, i): coef[source 4k+g][unknown i] -- a fully coalesced
-// 512-byte read of the coefficient stream), B = the gathered rows (lane (g, j): 4 doubles of source 4k+g).
-// The in-block triangular solve is 4 more K-steps with A = inverse of the block's 16 x 16 triangle and B = acc itself
-// (C/D register s IS the B operand of K-step s), so nothing ever crosses lanes.
+// 4*s + g, columns cw + NT*j + nt for the NT tiles nt (every lane owns NT CONSECUTIVE doubles of a row: one 8-, 16- or
+// two 16-byte accesses).  One K-step consumes 4 sources: A = coefficients (lane (g, i): coef[source 4k+g][unknown i] --
+// a fully coalesced 512-byte read of the coefficient stream), B = the gathered rows (lane (g, j): NT doubles of source
+// 4k+g).  The in-block triangular solve is 4 more K-steps with A = inverse of the block's 16 x 16 triangle and B = acc
+// itself (C/D register s IS the B operand of K-step s), so nothing ever crosses lanes.
 //
-// Sources are consumed in STAGES of 16 (4 K-steps, 16 MFMAs).  The loads of stage s+1 (16 row pieces, 4 coefficient
-// vectors) and the ids of stage s+2 are issued before the MFMAs of stage s; every load is unconditional (stage numbers
-// are clamped), so the compiler's vmcnt bookkeeping stays exact and a stage's MFMAs wait for that stage's loads only.
-struct Stage {
-    double a[4];
-    f64x2 lo[4], hi[4];
+// NT = 4 (64 columns per wavefront) where a level has work for the whole chip; NT = 1 on the long tail of levels with
+// a few dozen blocks: there a workgroup's own matrix-core time IS the launch's duration (one f64 MFMA occupies its SIMD
+// for 64 cycles; a 1024-source block is 1024 of them per 64 columns), and 16-column wavefronts put four times as many
+// compute units to work on it.
+//
+// What else bounds a block is the number of DEPENDENT round trips to memory, so the path is written as two of them:
+//   1. the record (header, destination / initial-value ids, the ids of every source of this wavefront),
+//   2. the initial rows, the triangle, and the rows and coefficients of the first D slots of the RING below,
+// after which the ring keeps D slots of Q K-steps in flight: a slot is multiplied and immediately re-filled with the
+// loads of the slot D places ahead.  The rules that keep the hardware's load counter exact (and the waits minimal):
+// every load is unconditional (slots past the end read row 0), no loaded value is post-processed before its use (the
+// sum is accumulated with the coefficients' own sign: acc = sum - init, negated once at the end), ring slots are
+// compile-time registers (the loop is unrolled over the ring), and sched_barriers pin the order in which loads are
+// issued.  Source ids never travel again: they sit in the wavefront's record registers and reach the lane that needs
+// them through ds_bpermute.
+template <int NT>
+struct Piece {  // NT consecutive doubles of a row
+    double v[NT];
+};
+
+template <int Q, int NT>
+struct Slot {
+    double a[Q];
+    Piece<NT> b[Q];
 };
 
 struct PanelCtx {
-    const int32_t *sidx;  // source ids of the block
+    const int32_t *sidx;  // source ids of the block (pool)
     const double *cf;     // source coefficients of the block
     const double *X, *S;
+    const char *Xl, *Sl;  // FAST: this lane's piece of row 0 of X / of the scratch rows (lanes without columns: column 0)
     int64_t ldx, lds;
+    uint32_t ldx8, lds8;  // row pitch in bytes
     int g, lane, cb, nrhs;
-    bool in;              // this lane's 4 columns exist (FAST: all or none)
+    bool in;              // this lane's NT columns exist (FAST: all or none)
 };
 
-__device__ __forceinline__ void load_ids(int32_t (&id)[4], const PanelCtx &c, int st)
+// this lane's piece of row `id`: FAST layout (aligned, whole pieces) with one 64-bit multiply-add per address
+template <bool FAST, int NT>
+__device__ __forceinline__ Piece<NT> load_piece(int32_t id, const PanelCtx &c)
 {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) id[q] = c.sidx[st * 16 + 4 * q + c.g];
-}
-
-template <bool FAST>
-__device__ __forceinline__ void load_stage(Stage &R, const int32_t (&id)[4], const PanelCtx &c, int st)
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        R.a[q] = -c.cf[(int64_t)(st * 16 + 4 * q) * 16 + c.lane];
-        const double *p = row_ptr(id[q], c.X, c.ldx, c.S, c.lds);
-        if (FAST) {  // 16-byte aligned rows, nrhs a multiple of 4: lanes without columns re-read column 0
-            p += c.in ? c.cb : 0;
-            R.lo[q] = *reinterpret_cast<const f64x2 *>(p);
-            R.hi[q] = *reinterpret_cast<const f64x2 *>(p + 2);
+    Piece<NT> r;
+    if (FAST) {
+        const bool x = id >= 0;
+        const uint32_t row = (uint32_t)(x ? id : ~id);
+        const char *p = (x ? c.Xl : c.Sl) + (uint64_t)row * (uint64_t)(x ? c.ldx8 : c.lds8);
+        if constexpr (NT == 4) {
+            const f64x2 lo = *reinterpret_cast<const f64x2 *>(p), hi = *reinterpret_cast<const f64x2 *>(p + 16);
+            r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = hi.x; r.v[3] = hi.y;
+        } else if constexpr (NT == 2) {
+            const f64x2 lo = *reinterpret_cast<const f64x2 *>(p);
+            r.v[0] = lo.x; r.v[1] = lo.y;
         } else {
-            p += c.cb;
-            R.lo[q].x = c.cb + 0 < c.nrhs ? p[0] : 0.0;
-            R.lo[q].y = c.cb + 1 < c.nrhs ? p[1] : 0.0;
-            R.hi[q].x = c.cb + 2 < c.nrhs ? p[2] : 0.0;
-            R.hi[q].y = c.cb + 3 < c.nrhs ? p[3] : 0.0;
+            r.v[0] = *reinterpret_cast<const double *>(p);
         }
+    } else {
+        const double *p = row_ptr(id, c.X, c.ldx, c.S, c.lds) + c.cb;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) r.v[nt] = c.cb + nt < c.nrhs ? p[nt] : 0.0;
+    }
+    return r;
+}
+
+// K-steps [slot * Q, ...) of the current WINDOW, whose ids the record registers (ids0, ids1) hold (16 K-steps per
+// register); `slot` and `nslots` count inside the window.  Slots past the end read row 0 of X (never used).
+template <bool FAST, int Q, int NT>
+__device__ __forceinline__ void load_slot(Slot<Q, NT> &R, int32_t ids0, int32_t ids1, const PanelCtx &c, const double *cfw, int slot, int nslots)
+{
+    const bool valid = slot < nslots;  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int k = slot * Q + q;
+        int32_t id = __builtin_amdgcn_ds_bpermute(((4 * k + c.g) & 63) << 2, (k & 16) ? ids1 : ids0);
+        id = valid ? id : 0;
+        R.a[q] = cfw[(valid ? (int64_t)k * 64 : 0) + c.lane];
+        R.b[q] = load_piece<FAST, NT>(id, c);
     }
 }
 
-__device__ __forceinline__ void mfma_stage(f64x4 (&acc)[4], const Stage &R)
+template <int Q, int NT>
+__device__ __forceinline__ void mfma_slot(f64x4 (&acc)[NT], const Slot<Q, NT> &R)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].x, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].y, acc[3], 0, 0, 0);
-    }
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.b[q].v[nt], acc[nt], 0, 0, 0);
 }
 
-// ids and triangle of a block, fetched in the same round trip as the first source ids
+// ids and triangle of a block
 struct PanelIds {
-    int32_t init[4], dest[4];  // unknown 4s + g for s = 0..3
-    double tinv[4];            // A operands of the inverse triangle
+    int32_t dest[4];  // unknown 4s + g for s = 0..3
+    double tinv[4];   // A operands of the inverse triangle
 };
 
 __device__ __forceinline__ void load_panel_tinv(PanelIds &P, const BlockHeader h, const PanelCtx &c)
@@ -216,131 +266,34 @@ __device__ __forceinline__ void load_panel_tinv(PanelIds &P, const BlockHeader h
     for (int k = 0; k < 4; ++k) P.tinv[k] = tinv[k * 64 + c.lane];
 }
 
-__device__ __forceinline__ void panel_ids_from(PanelIds &P, const Prologue &R, const PanelCtx &c, bool lead)
+// initial rows of the block -> v (register s <- unknown 4s + g); the loads are unconditional (rows that do not exist
+// read row 0 and are zeroed afterwards), so all of them travel together with the ring's first slots
+template <bool FAST, int NT>
+__device__ __forceinline__ void panel_load_init(f64x4 (&v)[NT], const Prologue &R, const PanelCtx &c, bool lead)
 {
+    int32_t id[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        P.dest[s] = word_at(R.r0, 8 + 4 * s + c.g);
-        const int32_t init = word_at(R.r0, 24 + 4 * s + c.g);
-        P.init[s] = lead ? init : RSP_NONE;
+        id[s] = word_at(R.r0, 24 + 4 * s + c.g);
+        if (!lead) id[s] = RSP_NONE;
     }
-}
-
-// rows of the block -> acc (register s <- unknown 4s + g); kNone = zero
-template <bool FAST>
-__device__ __forceinline__ void panel_load_rows(f64x4 (&acc)[4], const int32_t (&id4)[4], const PanelCtx &c)
-{
+    Piece<NT> piece[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) piece[s] = load_piece<FAST, NT>(id[s] != RSP_NONE ? id[s] : 0, c);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int32_t id = id4[s];
-        double v[4] = {0.0, 0.0, 0.0, 0.0};
-        if (id != RSP_NONE) {
-            const double *p = row_ptr(id, c.X, c.ldx, c.S, c.lds) + c.cb;
-            if (FAST) {
-                if (c.in) {
-                    const f64x2 lo = *reinterpret_cast<const f64x2 *>(p), hi = *reinterpret_cast<const f64x2 *>(p + 2);
-                    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
-                }
-            } else {
+        const bool have = id[s] != RSP_NONE && (!FAST || c.in);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    if (c.cb + nt < c.nrhs) v[nt] = p[nt];
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt][s] = v[nt];
-    }
-}
-
-// acc = init rows - coef[st_begin*16 .. st_end*16) * sources.  `lead`: this wavefront loads the initial values.
-// PIPE: two stages of registers, the next stage's loads in flight during this stage's MFMAs -- the shortest critical
-// path, for levels with little work.  !PIPE: one stage of registers (half the footprint, twice the wavefronts per CU):
-// a stage's loads are only issued after the previous stage's MFMAs, and it is the OTHER wavefronts of the CU that
-// cover the wait -- the better trade on levels with thousands of blocks, where throughput is what counts.
-// Lean variant with HALF stages (PIPE == 2): the same 16 sources' worth of registers as the one-stage lean variant, but as
-// two half stages of 8 that alternate -- while one half is multiplied the other one is in flight, and the ids run two
-// halves ahead, so a wavefront never sits with nothing outstanding.
-struct HalfStage {
-    double a[2];
-    f64x2 lo[2], hi[2];
-};
-
-__device__ __forceinline__ void load_half_ids(int32_t (&id)[2], const PanelCtx &c, int hs)
-{
-#pragma unroll
-    for (int q = 0; q < 2; ++q) id[q] = c.sidx[hs * 8 + 4 * q + c.g];
-}
-
-template <bool FAST>
-__device__ __forceinline__ void load_half(HalfStage &R, const int32_t (&id)[2], const PanelCtx &c, int hs)
-{
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        R.a[q] = -c.cf[(int64_t)(hs * 8 + 4 * q) * 16 + c.lane];
-        const double *p = row_ptr(id[q], c.X, c.ldx, c.S, c.lds);
-        if (FAST) {
-            p += c.in ? c.cb : 0;
-            R.lo[q] = *reinterpret_cast<const f64x2 *>(p);
-            R.hi[q] = *reinterpret_cast<const f64x2 *>(p + 2);
-        } else {
-            p += c.cb;
-            R.lo[q].x = c.cb + 0 < c.nrhs ? p[0] : 0.0;
-            R.lo[q].y = c.cb + 1 < c.nrhs ? p[1] : 0.0;
-            R.hi[q].x = c.cb + 2 < c.nrhs ? p[2] : 0.0;
-            R.hi[q].y = c.cb + 3 < c.nrhs ? p[3] : 0.0;
-        }
-    }
-}
-
-__device__ __forceinline__ void mfma_half(f64x4 (&acc)[4], const HalfStage &R)
-{
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.lo[q].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].x, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(R.a[q], R.hi[q].y, acc[3], 0, 0, 0);
-    }
-}
-
-// stages [st_begin, st_end) of 16 sources = half stages [2 st_begin, 2 st_end); the record holds the ids of the first two
-template <bool FAST>
-__device__ __forceinline__ void gather_halves(f64x4 (&acc)[4], const Prologue &R, const PanelCtx &c, int st_begin, int st_end)
-{
-    if (st_begin >= st_end) return;  // wave-uniform
-    const int h0 = 2 * st_begin, hend = 2 * st_end, hlast = hend - 1;
-    int32_t idA[2], idB[2], idA2[2], idB2[2];
-    HalfStage A, B;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        idA[q] = word_at(R.r0, 40 + 4 * q + c.g);
-        idB[q] = word_at(R.r0, 48 + 4 * q + c.g);
-    }
-    load_half_ids(idA2, c, min(h0 + 2, hlast));
-    load_half_ids(idB2, c, min(h0 + 3, hlast));
-    load_half<FAST>(A, idA, c, h0);
-    load_half<FAST>(B, idB, c, h0 + 1);
-    for (int hs = h0; hs < hend; hs += 2) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            idA[q] = idA2[q];
-            idB[q] = idB2[q];
-        }
-        load_half_ids(idA2, c, min(hs + 4, hlast));
-        load_half_ids(idB2, c, min(hs + 5, hlast));
-        mfma_half(acc, A);
-        load_half<FAST>(A, idA, c, min(hs + 2, hlast));
-        mfma_half(acc, B);
-        load_half<FAST>(B, idB, c, min(hs + 3, hlast));
+        for (int nt = 0; nt < NT; ++nt) v[nt][s] = have ? piece[s].v[nt] : 0.0;
     }
 }
 
 // ONE right-hand side: nothing but latency counts (a level is a handful of wavefronts waiting for a handful of doubles),
 // and registers are plentiful because only column 0 exists.  All stages of the wavefront (at most DEPTH per batch) are
 // fetched at once -- every id in one round trip, then every row and coefficient in one more -- instead of one
-// dependent gather per stage; only the first of the four column tiles is computed.
+// dependent gather per stage; only the first column tile is computed.
 template <int DEPTH>
-__device__ __forceinline__ void panel_gather_single(f64x4 (&acc)[4], const PanelCtx &c, int st_begin, int st_end)
+__device__ __forceinline__ void panel_gather_single(f64x4 &acc0, const PanelCtx &c, int st_begin, int st_end)
 {
     const bool mine = (c.lane & 15) == 0;  // lanes (g, 0) hold the B operand of column 0
     for (int s0 = st_begin; s0 < st_end; s0 += DEPTH) {
@@ -352,7 +305,7 @@ __device__ __forceinline__ void panel_gather_single(f64x4 (&acc)[4], const Panel
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 id[d][q] = c.sidx[st * 16 + 4 * q + c.g];
-                a[d][q] = -c.cf[(int64_t)(st * 16 + 4 * q) * 16 + c.lane];
+                a[d][q] = c.cf[(int64_t)(st * 16 + 4 * q) * 16 + c.lane];
             }
         }
 #pragma unroll
@@ -363,73 +316,99 @@ __device__ __forceinline__ void panel_gather_single(f64x4 (&acc)[4], const Panel
         for (int d = 0; d < DEPTH; ++d)
             if (s0 + d < st_end) {  // wave-uniform
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][q], b[d][q], acc[0], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][q], b[d][q], acc0, 0, 0, 0);
             }
     }
 }
 
-template <bool FAST, int PIPE>
-__device__ __forceinline__ void panel_gather(f64x4 (&acc)[4], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
+// acc = coef[st_begin*16 .. st_end*16) * sources - initial rows (the caller negates).  `lead`: this wavefront owns the
+// initial values.  LAT: the latency variant (levels with few workgroups: a deep ring, the triangle fetched up front);
+// otherwise the lean one (4 slots of 4 sources, half the registers, twice the wavefronts per CU, initial rows and
+// triangle fetched at the end).  NL: id lines of the record.
+template <bool FAST, bool LAT, int NL, int NT>
+__device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) P.dest[s] = word_at(R.r0, 8 + 4 * s + c.g);
     if (!FAST && c.nrhs == 1) {  // wave-uniform
-        panel_ids_from(P, R, c, lead);
-        panel_load_rows<false>(acc, P.init, c);
+        panel_load_init<false, NT>(acc, R, c, lead);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = -acc[nt];
         load_panel_tinv(P, h, c);
-        panel_gather_single<PIPE == 1 ? 8 : 2>(acc, c, st_begin, st_end);
+        panel_gather_single<LAT ? 8 : 2>(acc[0], c, st_begin, st_end);
         return;
     }
-    const int last = st_end - 1;
-    const bool any = st_begin < st_end;  // wave-uniform; a block may have no sources at all
-    int32_t idA[4];
-    Stage A;
-    // the record holds the block's ids and those of this wavefront's first stage (and the one after it)
-    panel_ids_from(P, R, c, lead);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) idA[q] = word_at(R.r0, 40 + 4 * q + c.g);
-    if (PIPE == 2) {
-        panel_load_rows<FAST>(acc, P.init, c);
-        gather_halves<FAST>(acc, R, c, st_begin, st_end);
+    // K-steps per slot, slots of the ring (NT = 4: 10 registers per K-step; NT = 1: 4)
+    constexpr int Q = LAT ? 2 : 1, D = LAT ? 7 : 4;
+    constexpr int WIN = 16 * NL;  // K-steps whose ids the record registers hold
+    const int nks = (st_end - st_begin) * 4;  // K-steps of this wavefront
+    const double *cfw = c.cf + (int64_t)st_begin * 256;
+    // LAT: the initial rows travel with the ring's first slots and start the sum (acc = -init); lean: registers are
+    // short, the initial rows are fetched at the end together with the triangle (one round trip either way)
+    // (the sched_barriers pin the ORDER in which loads are issued: loads return in order, and the compiler's scheduler
+    // would otherwise happily issue the slot that is needed first last)
+    if (LAT) {
+        panel_load_init<FAST, NT>(acc, R, c, lead);
         load_panel_tinv(P, h, c);
-    } else if (PIPE == 1) {
-        int32_t idB[4];
-        Stage B;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int32_t ids0 = R.ids0, ids1 = NL >= 2 ? R.ids1 : 0;
+    Slot<Q, NT> ring[D];
+    {
+        const int nslots = min(nks, WIN) / Q;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) idB[q] = word_at(R.r1, 4 * q + c.g);  // used only if the wavefront has a second stage
-        // round trip 2
-        panel_load_rows<FAST>(acc, P.init, c);
-        load_panel_tinv(P, h, c);
-        if (!any) return;
-        load_stage<FAST>(A, idA, c, st_begin);
-        for (int s = st_begin; s < st_end; s += 2) {
-            load_stage<FAST>(B, idB, c, min(s + 1, last));
-            load_ids(idA, c, min(s + 2, last));
-            mfma_stage(acc, A);
-            load_stage<FAST>(A, idA, c, min(s + 2, last));
-            load_ids(idB, c, min(s + 3, last));
-            if (s + 1 < st_end) mfma_stage(acc, B);
+        for (int d = 0; d < D; ++d) {
+            load_slot<FAST, Q, NT>(ring[d], ids0, ids1, c, cfw, d, nslots);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    } else {
-        panel_load_rows<FAST>(acc, P.init, c);
-        if (any) {
-            load_stage<FAST>(A, idA, c, st_begin);
-            for (int s = st_begin; s < st_end; ++s) {
-                load_ids(idA, c, min(s + 1, last));
-                mfma_stage(acc, A);
-                load_stage<FAST>(A, idA, c, min(s + 1, last));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = LAT ? -acc[nt] : f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int w0 = 0;;) {
+        const int nslots = min(nks - w0, WIN) / Q;
+        for (int base = 0; base < nslots; base += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (base + d < nslots) mfma_slot<Q, NT>(acc, ring[d]);  // wave-uniform
+                load_slot<FAST, Q, NT>(ring[d], ids0, ids1, c, cfw, base + d + D, nslots);
+                __builtin_amdgcn_sched_barrier(0);  // keep the re-fill where it is: right behind the slot's last use
             }
         }
+        w0 += WIN;
+        if (w0 >= nks) break;
+        // a wavefront with more sources than its record holds (only when one wavefront runs a long block alone): the
+        // next window's ids come from the pool, the ring starts over
+        cfw += (int64_t)WIN * 64;
+        const int32_t *sw = c.sidx + (int64_t)st_begin * 16 + (int64_t)w0 * 4;
+        const int left = (nks - w0) * 4;
+        ids0 = sw[min(c.lane, left - 1)];
+        if (NL >= 2) ids1 = sw[min(64 + c.lane, left - 1)];
+        const int nnext = min(nks - w0, WIN) / Q;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            load_slot<FAST, Q, NT>(ring[d], ids0, ids1, c, cfw, d, nnext);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!LAT && lead) {  // wave-uniform
+        f64x4 init[NT];
+        panel_load_init<FAST, NT>(init, R, c, true);
         load_panel_tinv(P, h, c);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] -= init[nt];
     }
 }
 
-// in-block triangle (as its inverse) and the store of the 16 unknowns
-template <bool FAST>
-__device__ __forceinline__ void panel_finish(f64x4 (&acc)[4], const PanelIds &P, const BlockHeader h, const PanelCtx &c, double *X, double *S)
+// acc -> -acc, in-block triangle (as its inverse) and the store of the 16 unknowns
+template <bool FAST, int NT>
+__device__ __forceinline__ void panel_finish(f64x4 (&acc)[NT], const PanelIds &P, const BlockHeader h, const PanelCtx &c, double *X, double *S)
 {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = -acc[nt];
     if (h.has_tri) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             f64x4 r = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < 4; ++k) r = __builtin_amdgcn_mfma_f64_16x16x4f64(P.tinv[k], acc[nt][k], r, 0, 0, 0);
@@ -443,18 +422,25 @@ __device__ __forceinline__ void panel_finish(f64x4 (&acc)[4], const PanelIds &P,
             double *p = const_cast<double *>(row_ptr(id, X, c.ldx, S, c.lds)) + c.cb;
             if (FAST) {
                 if (c.in) {
-                    *reinterpret_cast<f64x2 *>(p) = f64x2{acc[0][s], acc[1][s]};
-                    *reinterpret_cast<f64x2 *>(p + 2) = f64x2{acc[2][s], acc[3][s]};
+                    if constexpr (NT == 4) {
+                        *reinterpret_cast<f64x2 *>(p) = f64x2{acc[0][s], acc[1][s]};
+                        *reinterpret_cast<f64x2 *>(p + 2) = f64x2{acc[2][s], acc[3][s]};
+                    } else if constexpr (NT == 2) {
+                        *reinterpret_cast<f64x2 *>(p) = f64x2{acc[0][s], acc[1][s]};
+                    } else {
+                        p[0] = acc[0][s];
+                    }
                 }
             } else {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
                     if (c.cb + nt < c.nrhs) p[nt] = acc[nt][s];
             }
         }
     }
 }
 
+template <int NT>
 __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArrays &B, const double *X, int64_t ldx, const double *S,
                                              int64_t lds, int cw, int nrhs, int lane)
 {
@@ -467,21 +453,25 @@ __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArr
     c.lds = lds;
     c.g = lane >> 4;
     c.lane = lane;
-    c.cb = cw + 4 * (lane & 15);
+    c.cb = cw + NT * (lane & 15);
     c.nrhs = nrhs;
-    c.in = c.cb + 4 <= nrhs;
+    c.in = c.cb + NT <= nrhs;
+    c.ldx8 = (uint32_t)(ldx * 8);
+    c.lds8 = (uint32_t)(lds * 8);
+    c.Xl = reinterpret_cast<const char *>(X + (c.in ? c.cb : 0));
+    c.Sl = reinterpret_cast<const char *>(S + (c.in ? c.cb : 0));
     return c;
 }
 
-template <bool FAST, int PIPE>
+template <bool FAST, bool LAT, int NT>
 __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const Prologue &R, const BlockArrays &B, double *X, int64_t ldx, double *S,
                                                int64_t lds, int cw, int nrhs, int lane)
 {
-    const PanelCtx c = make_ctx(h, B, X, ldx, S, lds, cw, nrhs, lane);
+    const PanelCtx c = make_ctx<NT>(h, B, X, ldx, S, lds, cw, nrhs, lane);
     PanelIds P;
-    f64x4 acc[4];
-    panel_gather<FAST, PIPE>(acc, P, R, h, c, 0, h.nsrc >> 4, true);
-    panel_finish<FAST>(acc, P, h, c, X, S);
+    f64x4 acc[NT];
+    panel_gather<FAST, LAT, 1, NT>(acc, P, R, h, c, 0, h.nsrc >> 4, true);
+    panel_finish<FAST, NT>(acc, P, h, c, X, S);
 }
 
 // ---- one launch per level ----------------------------------------------------------------------------------------
@@ -497,31 +487,32 @@ __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const Prolog
 struct LevelDesc {
     int64_t task_begin;      // class 0: first task
     int64_t block_begin[2];  // classes 1, 2: first block (one block per task)
-    int64_t blk0, rec0;      // class 0: first block and its prologue record (records follow the block order)
-    int64_t rec_begin[2];    // classes 1, 2: record of the first block (4 / 8 records per block)
+    int64_t blk0, rec0;      // class 0: first block and the LINE of its prologue record (records follow the block order, 2 lines each)
+    int64_t rec_begin[2];    // split classes: line of the first block's first record (4 records of 2 lines / 8 records of 3 lines per block)
     int ntasks, nblk[2];
     int wg0, wg1, wg2;       // workgroups per class
     int single;              // every class-0 task is one block: block = blk0 + task, no task_ptr lookup
 };
 
-// class 0: the blocks of a task run in order.  t = task number inside the launch.
-template <bool FAST, int PIPE>
+// class 0: the blocks of a task run in order.  t = task number inside the launch.  A wavefront owns 16 NT columns; the
+// vector path (one column per lane) then uses the first 16 NT lanes only.
+template <bool FAST, bool LAT, int NT>
 __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task_begin, int t, int64_t blk0, int64_t rec0, bool single, int chunk,
                                          double *X, int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
-    const int cw = chunk * 64;
+    const int cw = chunk * 16 * NT;
     const int col = cw + lane;
-    const bool live = col < nrhs;
+    const bool live = col < nrhs && lane < 16 * NT;
     int64_t b = blk0 + t, bend = b + 1;
     if (!single) {
         b = B.task_ptr[task_begin + t];
         bend = B.task_ptr[task_begin + t + 1];
     }
     for (; b < bend; ++b) {
-        const Prologue R = load_prologue<PIPE == 1>(B, rec0 + (b - blk0), lane);
+        const Prologue R = load_prologue<2, 1>(B, rec0 + 2 * (b - blk0), lane);
         const BlockHeader h = header_of(R);
         switch (h.rc) {
-            case 16: run_block_mfma<FAST, PIPE>(h, R, B, X, ldx, S, lds, cw, nrhs, lane); break;
+            case 16: run_block_mfma<FAST, LAT, NT>(h, R, B, X, ldx, S, lds, cw, nrhs, lane); break;
             case 1: run_block_vec<1>(h, R, B, X, ldx, S, lds, col, live, lane); break;
             case 2: run_block_vec<2>(h, R, B, X, ldx, S, lds, col, live, lane); break;
             default: run_block_vec<4>(h, R, B, X, ldx, S, lds, col, live, lane); break;
@@ -540,25 +531,26 @@ __device__ __forceinline__ void split_item(int q, int n, int nchunks, int &blk, 
 }
 
 // W wavefronts (w = 0..W-1) share one matrix-core block: contiguous ranges of its stages each, partial accumulators
-// meet in LDS (red: (W - 1) x 8 KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
-template <int W, bool FAST, int PIPE>
+// meet in LDS (red: (W - 1) x 2 NT KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
+template <int W, bool FAST, bool LAT, int NT>
 __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t rec, int chunk, int w, double *red, double *X,
                                           int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
     PanelIds P;
-    f64x4 acc[4];
+    f64x4 acc[NT];
     BlockHeader h;
     PanelCtx c;
     if (valid) {
-        const Prologue R = load_prologue<PIPE == 1>(B, rec + w, lane);  // this wavefront's record of the block
+        constexpr int NL = W == 8 ? 2 : 1;
+        const Prologue R = load_prologue<NL + 1, NL>(B, rec + (int64_t)w * (NL + 1), lane);  // this wavefront's record of the block
         h = header_of(R);
-        c = make_ctx(h, B, X, ldx, S, lds, chunk * 64, nrhs, lane);
+        c = make_ctx<NT>(h, B, X, ldx, S, lds, chunk * 16 * NT, nrhs, lane);
         const int nst = h.nsrc >> 4;
-        panel_gather<FAST, PIPE>(acc, P, R, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
+        panel_gather<FAST, LAT, NL, NT>(acc, P, R, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
         if (w > 0) {
-            double *mine = red + (size_t)(w - 1) * 1024 + lane;
+            double *mine = red + (size_t)(w - 1) * 256 * NT + lane;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) mine[(nt * 4 + s) * 64] = acc[nt][s];
         }
@@ -566,13 +558,13 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
     __syncthreads();
     if (valid && w == 0) {
         for (int o = 0; o < W - 1; ++o) {
-            const double *theirs = red + (size_t)o * 1024 + lane;
+            const double *theirs = red + (size_t)o * 256 * NT + lane;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[nt][s] += theirs[(nt * 4 + s) * 64];
         }
-        panel_finish<FAST>(acc, P, h, c, X, S);
+        panel_finish<FAST, NT>(acc, P, h, c, X, S);
     }
 }
 
@@ -595,7 +587,7 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
         bend = B.task_ptr[task_begin + t + 1];
     }
     for (; b < bend; ++b) {
-        const Prologue R = load_prologue<false>(B, rec0 + (b - blk0), lane);
+        const Prologue R = load_prologue<2, 0>(B, rec0 + 2 * (b - blk0), lane);
         const BlockHeader h = header_of(R);
         switch (h.rc) {
             case 1: run_block_vec<1>(h, R, B, X, ldx, S, lds, col, live, lane); break;
@@ -605,11 +597,12 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
     }
 }
 
-template <bool FAST, int PIPE>
-__global__ __launch_bounds__(512, PIPE == 1 ? 2 : 4) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
-                                                    int nchunks)
+// nchunks counts chunks of 16 NT columns
+template <bool FAST, bool LAT, int NT>
+__global__ __launch_bounds__(512, LAT ? 2 : 4) void solve_level(BlockArrays B, LevelDesc L, double *X, int64_t ldx, double *S, int64_t lds, int nrhs,
+                                                                int nchunks)
 {
-    extern __shared__ double red[];  // 7 x 8 KiB
+    extern __shared__ double red[];  // 7 x 2 NT KiB
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..7
     const int per_xcd = (int)(gridDim.x >> 3);                              // the grid is a multiple of 8 workgroups
@@ -618,17 +611,18 @@ __global__ __launch_bounds__(512, PIPE == 1 ? 2 : 4) void solve_level(BlockArray
     if (item < L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
         int blk, chunk;
         split_item(item, L.nblk[1], nchunks, blk, chunk);
-        run_split<8, FAST, PIPE>(B, true, L.rec_begin[1] + (int64_t)blk * 8, chunk, w, red, X, ldx, S, lds, nrhs, lane);
+        run_split<8, FAST, LAT, NT>(B, true, L.rec_begin[1] + (int64_t)blk * 24, chunk, w, red, X, ldx, S, lds, nrhs, lane);
     } else if (item < L.wg2 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
         const int q = (item - L.wg2) * 2 + (w >> 2);
         const bool valid = q < L.nblk[0] * nchunks;
         int blk = 0, chunk = 0;
         if (valid) split_item(q, L.nblk[0], nchunks, blk, chunk);
-        run_split<4, FAST, PIPE>(B, valid, L.rec_begin[0] + (int64_t)blk * 4, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 1024, X, ldx, S, lds, nrhs, lane);
+        run_split<4, FAST, LAT, NT>(B, valid, L.rec_begin[0] + (int64_t)blk * 8, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 256 * NT, X, ldx, S, lds, nrhs,
+                                    lane);
     } else if (item < L.wg2 + L.wg1 + L.wg0) {  // 8 (task, chunk) pairs
         const int pair = (item - L.wg2 - L.wg1) * 8 + w;
         const int t = pair / nchunks;
-        if (t < L.ntasks) run_task<FAST, PIPE>(B, L.task_begin, t, L.blk0, L.rec0, L.single != 0, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
+        if (t < L.ntasks) run_task<FAST, LAT, NT>(B, L.task_begin, t, L.blk0, L.rec0, L.single != 0, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
     }
 }
 

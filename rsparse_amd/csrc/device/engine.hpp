@@ -230,7 +230,6 @@ constexpr i64 kTaskEntriesSingle = 512;
 constexpr i64 kLeanLaunchWorkgroups = 128;  // levels with at least this many 512-thread workgroups run the lean variant
 constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 right-hand sides: 3 parts are 2 % faster but re-read the
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)
-constexpr i64 kLeanMode = 2;  // lean variant of solve_level: 0 = one 16-source stage, 2 = two alternating 8-source half stages
 constexpr i64 kLeanLaunchWorkgroupsSingle = 128;  // the same switch for a single right-hand side (deep-fetch gather)
 constexpr i64 kSupernodal = 0;    // multi-right-hand-side programme: 0 blocked, 1 supernodal, 2 supernodal when it needs at most kSupernodalMaxLaunches
 constexpr i64 kSupernodalMaxLaunches = 300;

@@ -518,16 +518,28 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             L.ntasks = n01;
             L.nblk[0] = lv.ntasks[2];
             L.nblk[1] = lv.ntasks[3];
-            L.wg0 = (int)(((i64)n01 * nchunks + 7) / 8);
-            L.wg1 = (int)(((i64)lv.ntasks[2] * nchunks + 1) / 2);
-            L.wg2 = (int)((i64)lv.ntasks[3] * nchunks);
-            const unsigned wgs = (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
-            // few workgroups: latency counts, pipelined variant; many: the lean variant at twice the occupancy
+            auto wgs_for = [&](int chunks) {
+                L.wg0 = (int)(((i64)n01 * chunks + 7) / 8);
+                L.wg1 = (int)(((i64)lv.ntasks[2] * chunks + 1) / 2);
+                L.wg2 = (int)((i64)lv.ntasks[3] * chunks);
+                return (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
+            };
+            unsigned wgs = wgs_for(nchunks);
+            // Few workgroups: a workgroup's own chain (round trips, then its matrix-core time) is the launch's duration --
+            // the deep-ring variant, and 16 columns per wavefront instead of 64 so that four times as many compute units
+            // share the work.  Many: the lean variant at twice the occupancy.
             const bool pipe = wgs < (unsigned)(nrhs == 1 ? lean_wgs_single : lean_wgs);
-            static const i64 lean_mode = env_or("RSP_LEAN_MODE", kLeanMode);  // 0: one full stage, 2: two alternating half stages
-            auto kernel = fast ? (pipe ? dev::solve_level<true, 1> : lean_mode == 2 ? dev::solve_level<true, 2> : dev::solve_level<true, 0>)
-                               : (pipe ? dev::solve_level<false, 1> : lean_mode == 2 ? dev::solve_level<false, 2> : dev::solve_level<false, 0>);
-            hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, nchunks);
+            static const i64 narrow = env_or("RSP_LAT_NARROW", 1);
+            int level_chunks = nchunks;
+            const bool nt1 = pipe && narrow && nrhs > 16;
+            if (nt1) {
+                level_chunks = (int)((nrhs + 15) / 16);
+                wgs = wgs_for(level_chunks);
+            }
+            // (the element-wise path has no lean variant: its selects need the registers of the deep-ring one)
+            auto kernel = fast ? (nt1 ? dev::solve_level<true, true, 1> : pipe ? dev::solve_level<true, true, 4> : dev::solve_level<true, false, 4>)
+                               : (nt1 ? dev::solve_level<false, true, 1> : dev::solve_level<false, true, 4>);
+            hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, level_chunks);
             done += wgs;
         }
     }

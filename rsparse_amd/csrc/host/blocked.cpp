@@ -867,7 +867,7 @@ class Builder {
         P_.coef.resize(P_.coef.size() + 320, 0.0);
         // prologue records (sparse.hpp), in block order
         {
-            constexpr int PW = BlockProgram::kPrologueWords;
+            constexpr int LW = BlockProgram::kLineWords;
             const i64 nblocks = (i64)P_.hdr.size();
             P_.block_record.assign(nblocks + 1, 0);
             std::vector<int> waves(nblocks, 1);
@@ -875,29 +875,33 @@ class Builder {
                 for (int c = 2; c < NC; ++c)
                     for (i64 t = P_.level_class_ptr[NC * l + c]; t < P_.level_class_ptr[NC * l + c + 1]; ++t)
                         waves[P_.task_ptr[t]] = c == 2 ? 4 : 8;  // split classes: one block per task
-            for (i64 b = 0; b < nblocks; ++b) P_.block_record[b + 1] = P_.block_record[b] + waves[b];
-            P_.prologue.assign((size_t)P_.block_record[nblocks] * PW, 0);
+            for (i64 b = 0; b < nblocks; ++b) P_.block_record[b + 1] = P_.block_record[b] + waves[b] * BlockProgram::record_lines(waves[b]);
+            P_.prologue.assign((size_t)(P_.block_record[nblocks] + 1) * LW, 0);  // one spare line: the kernels load whole records
             for (i64 b = 0; b < nblocks; ++b) {
                 const BlockHeader &h = P_.hdr[b];
                 const int32_t *ids = P_.src_idx.data() + h.src_off;
                 const i64 nst = h.rc == 16 ? h.nsrc / 16 : 0;
+                const int lines = BlockProgram::record_lines(waves[b]);
                 for (int w = 0; w < waves[b]; ++w) {
-                    int32_t *rec = P_.prologue.data() + (size_t)(P_.block_record[b] + w) * PW;
-                    std::memcpy(rec, &h, sizeof(BlockHeader));
+                    int32_t *rec = P_.prologue.data() + (size_t)(P_.block_record[b] + (i64)w * lines) * LW;
+                    auto word = [&](int line, int l) -> int32_t & { return rec[(size_t)l * lines + line]; };  // interleaved: lane l owns words l*lines..
+                    int32_t head[8];
+                    std::memcpy(head, &h, sizeof(BlockHeader));
+                    for (int k = 0; k < 8; ++k) word(0, k) = head[k];
                     for (int r = 0; r < 16; ++r) {
-                        rec[8 + r] = r < h.rc ? ids[r] : kNone;
-                        rec[24 + r] = r < h.rc ? ids[h.rc + r] : kNone;
+                        word(0, 8 + r) = r < h.rc ? ids[r] : kNone;
+                        word(0, 24 + r) = r < h.rc ? ids[h.rc + r] : kNone;
                     }
                     const int32_t *sidx = ids + 2 * h.rc;
                     if (h.rc == 16) {
-                        const i64 first = std::min<i64>((nst * w) / waves[b], std::max<i64>(nst - 1, 0));
-                        const i64 second = std::min<i64>(first + 1, std::max<i64>(nst - 1, 0));
-                        for (int e = 0; e < 16; ++e) {
-                            rec[40 + e] = nst ? sidx[first * 16 + e] : 0;
-                            rec[64 + e] = nst ? sidx[second * 16 + e] : 0;
-                        }
+                        // the wavefront's own stages [first, last): every source id, in order
+                        // (a wavefront with more sources than its record holds fetches the later ones from the pool)
+                        const i64 first = (nst * w) / waves[b], last = (nst * (w + 1)) / waves[b];
+                        const i64 cnt = (last - first) * 16;
+                        for (i64 e = 0; e < (i64)(lines - 1) * LW; ++e)
+                            word(1 + (int)(e / LW), (int)(e % LW)) = cnt ? sidx[first * 16 + std::min(e, cnt - 1)] : 0;
                     } else {
-                        for (int e = 0; e < 16; ++e) rec[40 + e] = e < h.nsrc ? sidx[e] : 0;  // the vector path's first batch
+                        for (int e = 0; e < 16; ++e) word(0, 40 + e) = e < h.nsrc ? sidx[e] : 0;  // the vector path's first batch
                     }
                 }
             }
@@ -1084,24 +1088,30 @@ ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P)
                 const double *cf = P.coef.data() + h.coef_off;
                 // the prologue records the kernels actually read must say what the pools say
                 {
-                    constexpr int PW = BlockProgram::kPrologueWords;
+                    constexpr int LW = BlockProgram::kLineWords;
                     const bool have = (i64)P.block_record.size() == (i64)P.hdr.size() + 1 && P.block_record[bk] >= 0 &&
                                       P.block_record[bk + 1] > P.block_record[bk] &&
-                                      (size_t)P.block_record[bk + 1] * PW <= P.prologue.size();
-                    if (!have) {
+                                      (size_t)P.block_record[bk + 1] * LW <= P.prologue.size();
+                    const i64 span = have ? P.block_record[bk + 1] - P.block_record[bk] : 0;
+                    const i64 W = span == 2 ? 1 : span == 8 ? 4 : span == 24 ? 8 : 0;
+                    if (!have || !W) {
                         ++R.bad_index;
                     } else {
-                        const i64 W = P.block_record[bk + 1] - P.block_record[bk], nst = rc == 16 ? h.nsrc / 16 : 0;
+                        const i64 nst = rc == 16 ? h.nsrc / 16 : 0, lines = BlockProgram::record_lines((int)W);
                         for (i64 w = 0; w < W; ++w) {
-                            const int32_t *rec = P.prologue.data() + (size_t)(P.block_record[bk] + w) * PW;
-                            bool same = std::memcmp(rec, &h, sizeof(BlockHeader)) == 0;
-                            for (int r = 0; r < rc && r < 16; ++r) same = same && rec[8 + r] == ids[r] && rec[24 + r] == ids[rc + r];
-                            if (rc == 16 && nst) {
-                                const i64 first = (nst * w) / W, second = std::min(first + 1, nst - 1);
-                                for (int e = 0; e < 16; ++e)
-                                    same = same && rec[40 + e] == ids[32 + first * 16 + e] && rec[64 + e] == ids[32 + second * 16 + e];
-                            } else if (rc < 16) {
-                                for (int e = 0; e < 16 && e < h.nsrc; ++e) same = same && rec[40 + e] == ids[2 * rc + e];
+                            const int32_t *rec = P.prologue.data() + (size_t)(P.block_record[bk] + w * lines) * LW;
+                            auto word = [&](i64 line, i64 lane) { return rec[lane * lines + line]; };
+                            int32_t head[8];
+                            std::memcpy(head, &h, sizeof(BlockHeader));
+                            bool same = true;
+                            for (int k = 0; k < 8; ++k) same = same && word(0, k) == head[k];
+                            for (int r = 0; r < rc && r < 16; ++r) same = same && word(0, 8 + r) == ids[r] && word(0, 24 + r) == ids[rc + r];
+                            if (rc == 16) {
+                                const i64 first = (nst * w) / W, last = (nst * (w + 1)) / W;
+                                for (i64 e = 0; same && e < std::min<i64>((last - first) * 16, (lines - 1) * LW); ++e)
+                                    same = word(1 + e / LW, e % LW) == ids[32 + first * 16 + e];
+                            } else {
+                                for (int e = 0; e < 16 && e < h.nsrc; ++e) same = same && word(0, 40 + e) == ids[2 * rc + e];
                             }
                             if (!same) ++R.bad_index;
                         }

@@ -166,13 +166,21 @@ struct BlockProgram {
     std::vector<int32_t> src_idx;    // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
     std::vector<double> coef;
     // PROLOGUE records: what a wavefront needs before it can touch X, in one contiguous piece so that it costs ONE
-    // round trip instead of two dependent ones (header, then ids).  kPrologueWords int32 per record:
-    //   [0, 8) the BlockHeader itself, [8, 24) destination ids, [24, 40) initial-value ids (first rc of each used),
-    //   [40, 56) the ids of the record's FIRST stage of 16 sources, [64, 80) those of the following stage (clamped).
-    // A block of split class 2 / 3 has 4 / 8 consecutive records, one per wavefront (its first stage is
-    // (nsrc / 16) * w / W); all other blocks have one.  block_record[b] = index of block b's first record; records
-    // follow the block order, so inside one (level, class) range they are an arithmetic sequence.
-    static constexpr int kPrologueWords = 128;
+    // round trip instead of dependent ones (header, then ids, then more ids).  A record is 2 or 3 LINES of kLineWords
+    // int32 (a line is one coalesced 256-byte load of the wavefront):
+    //   line 0: [0, 8) the BlockHeader itself, [8, 24) destination ids, [24, 40) initial-value ids (first rc of each
+    //           used), [40, 56) vector blocks (rc < 16) only: the ids of the first 16 sources
+    //   line 1 (and 2): matrix-core blocks only: the ids of ALL sources of the record's wavefront, in order (the last
+    //           one repeated to the end of the line); a wavefront with more than 64 (two lines: 128) sources fetches
+    //           the later ones from the pool, 64 (128) at a time.
+    // A block of split class 2 / 3 has 4 / 8 consecutive records, one per wavefront w, which owns the 16-source stages
+    // [nst * w / W, nst * (w + 1) / W) of the block; all other blocks have one record.  Records of classes 0-2 have two
+    // lines, those of class 3 three (record_lines).  block_record[b] = LINE index of block b's first record; records
+    // follow the block order, so inside one (level, class) range they are an arithmetic sequence.  In memory the lines
+    // of a record are INTERLEAVED (word l of line i sits at l * lines + i), so that lane l fetches its word of every
+    // line with a single 8- or 12-byte load.
+    static constexpr int kLineWords = 64;
+    static constexpr int record_lines(int waves) { return waves == 8 ? 3 : 2; }
     std::vector<int32_t> prologue;
     std::vector<i64> block_record;   // per block, plus one past the end
     // clusters, sorted by level
