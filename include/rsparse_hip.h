@@ -36,7 +36,8 @@ enum rsp_status {
     RSP_NOT_POSITIVE_DEFINITE = 1, /* Error::NotPositiveDefinite, src/lib.rs:191 */
     RSP_NO_PIVOT = 2,              /* Error::NoPivot,             src/lib.rs:193 */
     RSP_BAD_INPUT = -1,            /* the reference would panic on a bounds check */
-    RSP_DEVICE_ERROR = -2          /* HIP error / no gfx950 device visible */
+    RSP_DEVICE_ERROR = -2,         /* HIP error / no gfx950 device visible */
+    RSP_INTERNAL_ERROR = -3        /* a defect of the library itself (an unexpected exception), never caused by the input */
 };
 
 /* which triangular system a handle solves; names follow the reference functions */
@@ -66,7 +67,12 @@ int rsp_usolve_f64(const rsp_csc_f64 *U, double *x);
 int rsp_utsolve_f64(const rsp_csc_f64 *U, double *x);
 
 /* ---- analyse-once / solve-many triangular handle (no reference counterpart: the reference
- *      re-walks the matrix on every call; this caches the device copy and the level schedule) ---- */
+ *      re-walks the matrix on every call; this caches the device copy and the level schedule) ----
+ * Thread safety (all handle types): any number of host threads may call into the library at once, on the same handle
+ * too.  Calls on ONE handle are serialised by a mutex in the handle, and a call on another stream than the handle's
+ * previous call first waits (on the device) for that call's kernels, because a handle's scratch rows and workspaces
+ * are shared by all of its calls.  Different handles are independent.  rsp_tri_solve_dev_noalloc_f64 is the one
+ * exception: it records nothing, see there. */
 typedef struct rsp_tri rsp_tri;
 int rsp_tri_analyze(const rsp_csc_f64 *T, int kind, rsp_tri **out);
 /* X = host, column-major n x nrhs with leading dimension ldx >= n; overwritten with the solutions */
@@ -117,13 +123,29 @@ int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *o
  * Returns RSP_OK when both agree, RSP_BAD_INPUT otherwise. */
 int rsp_selftest_host_threads(int64_t count, int threads, uint64_t seed);
 
+/* ---- gaxpy ------------------------------------------------------------------------------------
+ * rsparse::gaxpy (src/lib.rs:411-421): r = A x + y for one vector (host pointers; r may alias y). */
+int rsp_gaxpy_f64(const rsp_csc_f64 *A, const double *x, const double *y, double *r);
+/* The same for device-resident BLOCKS of right-hand sides (no reference counterpart: the reference has one vector at
+ * a time): A is uploaded once (row-wise), then  Y <- A X + beta Y  for X (n x nrhs) and Y (m x nrhs) in the given
+ * rsp_layout, asynchronously on `stream`.  beta = 1 is gaxpy; beta = -1 with Y = B gives the residual A X - B of a
+ * solved block; beta = 0 ignores Y's contents.  Entries of a row are added in ascending column order, as the
+ * reference's loop adds them. */
+typedef struct rsp_mat rsp_mat;
+int rsp_mat_create_f64(const rsp_csc_f64 *A, rsp_mat **M);
+int rsp_mat_gaxpy_dev_f64(const rsp_mat *M, const double *dX, int64_t ldx, double *dY, int64_t ldy, int64_t nrhs, int layout, double beta,
+                          void *stream);
+void rsp_mat_free(rsp_mat *M);
+
 /* ---- symbolic analysis (host CPU) -------------------------------------------------------------
  * rsparse::schol (src/lib.rs:968-986) and the LU branch of rsparse::sqr (src/lib.rs:1114-1119,1134-1137).
  * rsp_symb mirrors rsparse::data::Symb (src/data.rs:1022-1038). */
 typedef struct rsp_symb rsp_symb;
 int rsp_schol(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
 int rsp_sqr_lu(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
-/* build a Symb from caller-held vectors (pinv/q may be NULL = None) -- for chol(a, &mut s) with any s */
+/* build a Symb from caller-held vectors (pinv/q may be NULL = None) -- for chol(a, &mut s) with any s.
+ * RSP_BAD_INPUT unless pinv and q are permutations of 0..n-1, parent[k] is -1 or < n, cp[0] == 0 and every column of
+ * cp holds 1..n-k entries (the reference would panic on a bounds check where these are used as indices). */
 int rsp_symb_from_parts(int64_t n, const int64_t *pinv, const int64_t *q, const int64_t *parent, const int64_t *cp,
                         rsp_symb **S);
 int64_t rsp_symb_n(const rsp_symb *S);
@@ -153,7 +175,8 @@ int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int6
 int64_t rsp_chol_lnz(const rsp_chol *F);
 int rsp_chol_get_factor(const rsp_chol *F, int64_t *Lp, uint64_t *Li, double *Lx);
 /* info[0..9] = n, lnz, supernodes, supernodal levels, flops (sum of squared column counts), algorithmic bytes,
- *              lsolve levels, lsolve launches, ltsolve levels, ltsolve launches */
+ *              lsolve launches per sweep, lsolve tasks, ltsolve launches per sweep, ltsolve tasks (of the solve
+ *              programmes actually built: zeros before the first solve) */
 int rsp_chol_info(const rsp_chol *F, int64_t *info);
 /* last numeric-factorisation time measured with HIP events on the library's stream, milliseconds */
 double rsp_chol_factor_ms(const rsp_chol *F);
@@ -180,6 +203,9 @@ int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U);
 const int64_t *rsp_lu_pinv(const rsp_lu *N);   /* n entries */
 /* b <- A^-1 b for nrhs host column-major right-hand sides (ipvec, lsolve, usolve, ipvec: src/lib.rs:678-681) */
 int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs);
+/* the same for a device-resident block in either rsp_layout, asynchronously on `stream`: both permutations run on the
+ * device, nothing is copied to the host and nothing synchronises (S must be the Symb the factorisation was made with) */
+int rsp_lu_solve_dev_f64(rsp_lu *N, const rsp_symb *S, double *dB, int layout, int64_t ld, int64_t nrhs, void *stream);
 void rsp_lu_free(rsp_lu *N);
 int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol);
 

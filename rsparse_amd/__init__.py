@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     DeviceError,
     Error,
     LuHandle,
+    MatHandle,
     NoPivot,
     Nmrc,
     NotPositiveDefinite,
@@ -24,6 +25,7 @@ from .api import (  # noqa: F401
     cholsol,
     cholsol_batch,
     device_count,
+    gaxpy,
     lib,
     lsolve,
     ltsolve,

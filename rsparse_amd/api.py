@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librsparse_hip.so")
 
-RSP_OK, RSP_NOT_POSITIVE_DEFINITE, RSP_NO_PIVOT, RSP_BAD_INPUT, RSP_DEVICE_ERROR = 0, 1, 2, -1, -2
+RSP_OK, RSP_NOT_POSITIVE_DEFINITE, RSP_NO_PIVOT, RSP_BAD_INPUT, RSP_DEVICE_ERROR, RSP_INTERNAL_ERROR = 0, 1, 2, -1, -2, -3
 LSOLVE, LTSOLVE, USOLVE, UTSOLVE = 0, 1, 2, 3
 COL_MAJOR, ROW_MAJOR = 0, 1
 
@@ -98,6 +98,11 @@ def lib():
             "rsp_lu_U": (cint, [vp, csc]),
             "rsp_lu_pinv": (vp, [vp]),
             "rsp_lu_solve_f64": (cint, [vp, vp, vp, i64, i64]),
+            "rsp_lu_solve_dev_f64": (cint, [vp, vp, vp, cint, i64, i64, vp]),
+            "rsp_gaxpy_f64": (cint, [csc, vp, vp, vp]),
+            "rsp_mat_create_f64": (cint, [csc, C.POINTER(vp)]),
+            "rsp_mat_gaxpy_dev_f64": (cint, [vp, vp, i64, vp, i64, i64, cint, dbl, vp]),
+            "rsp_mat_free": (None, [vp]),
             "rsp_lu_free": (None, [vp]),
             "rsp_lusol_f64": (cint, [csc, vp, C.c_int8, dbl]),
         }
@@ -328,6 +333,10 @@ class LuHandle:
         assert B.dtype == np.float64 and (B.ndim == 1 or B.flags.f_contiguous)
         _check(lib().rsp_lu_solve_f64(self._h, self._s._h, B.ctypes.data, n, nrhs))
 
+    def solve_dev(self, ptr, layout, ld, nrhs, stream=None):
+        """Device-resident block (device pointer `ptr`) overwritten with A^-1 B; asynchronous on `stream`."""
+        _check(lib().rsp_lu_solve_dev_f64(self._h, self._s._h, ptr, layout, ld, nrhs, stream))
+
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.rsp_lu_free(self._h)
@@ -340,6 +349,36 @@ def lu(a, s, tol):
     h = C.c_void_p()
     _check(lib().rsp_lu_f64(C.byref(a._view()), s._h, tol, C.byref(h)))
     return LuHandle(h.value, s)
+
+
+def gaxpy(a, x, y):
+    """rsparse::gaxpy (src/lib.rs:411-421): returns A x + y (one vector), computed on the GPU."""
+    a = _as_sprs(a)
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.ascontiguousarray(y, np.float64)
+    assert x.shape == (a.n,) and y.shape == (a.m,)
+    r = np.empty(a.m)
+    _check(lib().rsp_gaxpy_f64(C.byref(a._view()), x.ctypes.data, y.ctypes.data, r.ctypes.data))
+    return r
+
+
+class MatHandle:
+    """A sparse matrix resident on the device for gaxpy over blocks of right-hand sides: Y <- A X + beta Y."""
+
+    def __init__(self, a):
+        a = _as_sprs(a)
+        self.m, self.n = a.m, a.n
+        h = C.c_void_p()
+        _check(lib().rsp_mat_create_f64(C.byref(a._view()), C.byref(h)))
+        self._h = h
+
+    def gaxpy_dev(self, x_ptr, ldx, y_ptr, ldy, nrhs, layout, beta=1.0, stream=None):
+        _check(lib().rsp_mat_gaxpy_dev_f64(self._h, x_ptr, ldx, y_ptr, ldy, nrhs, layout, beta, stream))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rsp_mat_free(self._h)
+            self._h = None
 
 
 def lusol(a, b, order, tol):

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -18,19 +19,56 @@
 
 using namespace rsp;
 
+// Every handle that solves carries a guard: a mutex around the host-side state a call touches (lazily built programmes,
+// workspace buffers) and an event that orders the DEVICE work of consecutive calls on different streams -- a handle's
+// scratch rows and workspaces are shared by all of its calls, so a call on another stream first waits for the previous
+// call's kernels.  Calls on one handle are therefore safe from any number of host threads; they do not overlap.
+struct UseGuard {
+    std::mutex m;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool used = false;
+    ~UseGuard()
+    {
+        if (done) (void)hipEventDestroy(done);
+    }
+    void begin(hipStream_t stream)
+    {
+        if (used && last != stream) RSP_HIP(hipStreamWaitEvent(stream, done, 0));
+    }
+    void end(hipStream_t stream)
+    {
+        if (!done) RSP_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        RSP_HIP(hipEventRecord(done, stream));
+        last = stream;
+        used = true;
+    }
+};
+
 struct rsp_tri {
     TriSolver solver;
+    UseGuard guard;
 };
 struct rsp_symb {
     Symbolic s;
 };
 struct rsp_chol {
     CholFactor f;
+    UseGuard guard;
+};
+struct rsp_mat {  // a sparse matrix resident on the device, row-wise (gaxpy / residuals of whole blocks)
+    int64_t m = 0, n = 0, nnz = 0;
+    DeviceBuffer<int64_t> ptr;
+    DeviceBuffer<int32_t> col;
+    DeviceBuffer<double> val;
 };
 struct rsp_lu {
     LuFactors f;
     std::unique_ptr<TriSolver> lower, upper;  // built on first solve
     bool single_use = false;                  // lusol: one solve, then dropped
+    DeviceBuffer<int64_t> d_pinv, d_q;        // rsp_lu_solve_dev_f64: the two permutations on the device
+    DeviceBuffer<double> work;
+    UseGuard guard;
 };
 
 namespace {
@@ -68,8 +106,13 @@ int guarded(F &&f)
         return RSP_DEVICE_ERROR;
     } catch (const std::bad_alloc &) {
         return RSP_DEVICE_ERROR;
-    } catch (...) {
+    } catch (const std::invalid_argument &) {  // what the library throws for input it rejects late
         return RSP_BAD_INPUT;
+    } catch (const std::exception &e) {  // anything else is a defect of the library, not of the caller's input
+        if (getenv("RSP_TIMING") || getenv("RSP_DEBUG")) fprintf(stderr, "rsparse_hip: internal error: %s\n", e.what());
+        return RSP_INTERNAL_ERROR;
+    } catch (...) {
+        return RSP_INTERNAL_ERROR;
     }
 }
 
@@ -113,6 +156,7 @@ const char *rsp_status_string(int status)
         case RSP_NO_PIVOT: return "Could not find a pivot";
         case RSP_BAD_INPUT: return "bad input";
         case RSP_DEVICE_ERROR: return "HIP device error (is a gfx950 GPU visible?)";
+        case RSP_INTERNAL_ERROR: return "internal error of the library (not caused by the input; please report)";
         default: return "unknown status";
     }
 }
@@ -148,7 +192,8 @@ int rsp_tri_solve_f64(rsp_tri *h, double *X, int64_t ldx, int64_t nrhs)
     if (!h || !X || nrhs < 0 || ldx < h->solver.n()) return RSP_BAD_INPUT;
     return guarded([&] {
         if (int st = require_device()) return st;
-        h->solver.solve_host(X, ldx, nrhs);
+        std::lock_guard<std::mutex> lock(h->guard.m);
+        h->solver.solve_host(X, ldx, nrhs);  // synchronous: returns with the device idle
         return (int)RSP_OK;
     });
 }
@@ -158,7 +203,10 @@ int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_
     if (!h || !dX || nrhs < 0 || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR)) return RSP_BAD_INPUT;
     if (layout == RSP_COL_MAJOR ? ld < h->solver.n() : ld < nrhs) return RSP_BAD_INPUT;
     return guarded([&] {
+        std::lock_guard<std::mutex> lock(h->guard.m);
+        h->guard.begin((hipStream_t)stream);
         h->solver.solve_device(dX, layout, ld, nrhs, (hipStream_t)stream);
+        h->guard.end((hipStream_t)stream);
         return (int)RSP_OK;
     });
 }
@@ -166,14 +214,25 @@ int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_
 int rsp_tri_solve_dev_noalloc_f64(rsp_tri *h, double *dX, int64_t ld, int64_t nrhs, void *stream)
 {
     if (!h || !dX || nrhs < 0 || ld < nrhs) return RSP_BAD_INPUT;
-    return guarded([&] { return h->solver.solve_device_noalloc(dX, ld, nrhs, (hipStream_t)stream); });
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(h->guard.m);  // host state only: no event is created or recorded here (nothing may allocate)
+        return h->solver.solve_device_noalloc(dX, ld, nrhs, (hipStream_t)stream);
+    });
 }
 
 int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int64_t ld, int64_t nrhs, void *stream)
 {
     if (!first || !second || !dX || nrhs < 0 || ld < nrhs || first->solver.n() != second->solver.n()) return RSP_BAD_INPUT;
     return guarded([&] {
+        // both handles, in address order (two threads pairing the same handles the other way round must not deadlock)
+        std::unique_lock<std::mutex> la(first < second ? first->guard.m : second->guard.m);
+        std::unique_lock<std::mutex> lb;
+        if (first != second) lb = std::unique_lock<std::mutex>(first < second ? second->guard.m : first->guard.m);
+        first->guard.begin((hipStream_t)stream);
+        if (first != second) second->guard.begin((hipStream_t)stream);
         solve_pair_device(first->solver, second->solver, dX, ld, nrhs, (hipStream_t)stream);
+        first->guard.end((hipStream_t)stream);
+        if (first != second) second->guard.end((hipStream_t)stream);
         return (int)RSP_OK;
     });
 }
@@ -221,9 +280,11 @@ int rsp_selftest_host_threads(int64_t count, int threads, uint64_t seed)
 {
     if (count < 0) return RSP_BAD_INPUT;
     return guarded([&] {
-        const char *old = getenv("RSP_HOST_THREADS");
-        const std::string keep = old ? old : "";
-        if (threads > 0) setenv("RSP_HOST_THREADS", std::to_string(threads).c_str(), 1);
+        struct Override {  // this thread only; the process environment is left alone (other threads read it)
+            int64_t keep;
+            explicit Override(int t) : keep(host_threads_override()) { if (t > 0) host_threads_override() = t; }
+            ~Override() { host_threads_override() = keep; }
+        } scoped(threads);
         std::vector<std::pair<uint64_t, uint32_t>> a((size_t)count);
         uint64_t z = seed;
         for (int64_t k = 0; k < count; ++k) {  // SplitMix64, keys with many ties, unique ordinals
@@ -242,10 +303,6 @@ int rsp_selftest_host_threads(int64_t count, int threads, uint64_t seed)
         });
         bool ok = a == b;
         for (int64_t k = 0; k < count && ok; ++k) ok = f[k] == k + 1;
-        if (threads > 0) {
-            if (old) setenv("RSP_HOST_THREADS", keep.c_str(), 1);
-            else unsetenv("RSP_HOST_THREADS");
-        }
         return ok ? (int)RSP_OK : (int)RSP_BAD_INPUT;
     });
 }
@@ -315,6 +372,86 @@ int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *o
     });
 }
 
+// ---- gaxpy on device-resident blocks ------------------------------------------------------------
+
+int rsp_mat_create_f64(const rsp_csc_f64 *A, rsp_mat **M)
+{
+    if (!sane_indices(A) || !M || A->n > INT32_MAX) return RSP_BAD_INPUT;
+    *M = nullptr;
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        std::unique_ptr<rsp_mat> h(new rsp_mat);
+        const int64_t m = A->m, n = A->n, nnz = A->p[n];
+        // CSC -> CSR by counting; inside a row the entries keep the order of their columns (the order the reference's
+        // column loop adds them to that row in), duplicates included
+        std::vector<int64_t> ptr((size_t)m + 1, 0);
+        for (int64_t e = 0; e < nnz; ++e) ptr[A->i[e] + 1]++;
+        for (int64_t r = 0; r < m; ++r) ptr[r + 1] += ptr[r];
+        std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+        std::vector<int32_t> col((size_t)nnz);
+        std::vector<double> val((size_t)nnz);
+        for (int64_t j = 0; j < n; ++j)
+            for (int64_t e = A->p[j]; e < A->p[j + 1]; ++e) {
+                const int64_t at = fill[A->i[e]]++;
+                col[at] = (int32_t)j;
+                val[at] = A->x[e];
+            }
+        h->m = m;
+        h->n = n;
+        h->nnz = nnz;
+        h->ptr.upload(ptr);
+        h->col.upload(col);
+        h->val.upload(val);
+        *M = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_mat_gaxpy_dev_f64(const rsp_mat *M, const double *dX, int64_t ldx, double *dY, int64_t ldy, int64_t nrhs, int layout, double beta,
+                          void *stream)
+{
+    if (!M || !dX || !dY || nrhs < 0 || nrhs > INT32_MAX || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR)) return RSP_BAD_INPUT;
+    if (layout == RSP_COL_MAJOR ? (ldx < M->n || ldy < M->m) : (ldx < nrhs || ldy < nrhs)) return RSP_BAD_INPUT;
+    if (nrhs == 0 || M->m == 0) return RSP_OK;
+    return guarded([&] {
+        const dev::CsrArrays A{M->ptr.get(), M->col.get(), M->val.get()};
+        if (layout == RSP_ROW_MAJOR) {
+            const int nchunks = (int)((nrhs + 63) / 64);
+            const int64_t wgs = (M->m * nchunks + 3) / 4;
+            if (wgs > INT32_MAX) return (int)RSP_BAD_INPUT;
+            hipLaunchKernelGGL(dev::gaxpy_rowmajor, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, A, M->m, dX, ldx, dY, ldy, (int)nrhs,
+                               nchunks, beta);
+        } else {
+            if (nrhs > 65535) return (int)RSP_BAD_INPUT;
+            hipLaunchKernelGGL(dev::gaxpy_colmajor, dim3((unsigned)((M->m + 255) / 256), (unsigned)nrhs), dim3(256), 0, (hipStream_t)stream, A,
+                               M->m, dX, ldx, dY, ldy, (int)nrhs, beta);
+        }
+        RSP_HIP(hipGetLastError());
+        return (int)RSP_OK;
+    });
+}
+
+void rsp_mat_free(rsp_mat *M) { delete M; }
+
+int rsp_gaxpy_f64(const rsp_csc_f64 *A, const double *x, const double *y, double *r)
+{
+    if (!sane_indices(A) || !x || !y || !r) return RSP_BAD_INPUT;
+    rsp_mat *M = nullptr;
+    int st = rsp_mat_create_f64(A, &M);
+    if (st == RSP_OK)
+        st = guarded([&] {
+            DeviceBuffer<double> dx, dy;
+            dx.upload(x, (size_t)A->n);
+            dy.upload(y, (size_t)A->m);
+            if (int s2 = rsp_mat_gaxpy_dev_f64(M, dx.get(), A->n, dy.get(), A->m, 1, RSP_COL_MAJOR, 1.0, nullptr)) return s2;
+            RSP_HIP(hipDeviceSynchronize());
+            dy.download(r, (size_t)A->m);
+            return (int)RSP_OK;
+        });
+    rsp_mat_free(M);
+    return st;
+}
+
 // ---- symbolic -----------------------------------------------------------------------------------
 
 int rsp_schol(const rsp_csc_f64 *A, int8_t order, rsp_symb **S)
@@ -345,6 +482,26 @@ int rsp_symb_from_parts(int64_t n, const int64_t *pinv, const int64_t *q, const 
 {
     if (n < 0 || !S) return RSP_BAD_INPUT;
     *S = nullptr;
+    // The vectors are used as indices later (chol writes Li[cp[..]++], lu reads A.p[q[k]]): reject anything that is not
+    // what schol / sqr would have produced -- the reference would panic on a bounds check there.
+    auto permutation = [n](const int64_t *v) {
+        std::vector<char> seen((size_t)n, 0);
+        for (int64_t k = 0; k < n; ++k) {
+            if (v[k] < 0 || v[k] >= n || seen[v[k]]) return false;
+            seen[v[k]] = 1;
+        }
+        return true;
+    };
+    if (pinv && !permutation(pinv)) return RSP_BAD_INPUT;
+    if (q && !permutation(q)) return RSP_BAD_INPUT;
+    if (parent)
+        for (int64_t k = 0; k < n; ++k)
+            if (parent[k] < -1 || parent[k] >= n) return RSP_BAD_INPUT;
+    if (cp) {
+        if (cp[0] != 0) return RSP_BAD_INPUT;
+        for (int64_t k = 0; k < n; ++k)  // every column of L holds at least its diagonal, at most n - k rows
+            if (cp[k + 1] < cp[k] + 1 || cp[k + 1] - cp[k] > n - k) return RSP_BAD_INPUT;
+    }
     return guarded([&] {
         std::unique_ptr<rsp_symb> h(new rsp_symb);
         Symbolic &s = h->s;
@@ -421,6 +578,7 @@ int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs)
 {
     if (!F || !B || nrhs < 0 || ldb < F->f.n()) return RSP_BAD_INPUT;
     return guarded([&] {
+        std::lock_guard<std::mutex> lock(F->guard.m);
         F->f.solve_host(B, ldb, nrhs);
         return (int)RSP_OK;
     });
@@ -431,7 +589,10 @@ int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int6
     if (!F || !dB || nrhs < 0 || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR)) return RSP_BAD_INPUT;
     if (layout == RSP_COL_MAJOR ? ld < F->f.n() : ld < nrhs) return RSP_BAD_INPUT;
     return guarded([&] {
+        std::lock_guard<std::mutex> lock(F->guard.m);
+        F->guard.begin((hipStream_t)stream);
         F->f.solve_device(dB, layout, ld, nrhs, permute != 0, (hipStream_t)stream);
+        F->guard.end((hipStream_t)stream);
         return (int)RSP_OK;
     });
 }
@@ -556,18 +717,25 @@ int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U)
 }
 const int64_t *rsp_lu_pinv(const rsp_lu *N) { return N ? N->f.pinv.data() : nullptr; }
 
+// the two triangular handles of a factorisation, built on its first solve (caller holds the guard)
+static int lu_solvers(rsp_lu *N)
+{
+    if (N->lower) return RSP_OK;
+    std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
+    if (int st = analyze_pair(*lo, N->f.L.view(), RSP_LSOLVE, *up, N->f.U.view(), RSP_USOLVE, N->single_use)) return st;
+    N->lower = std::move(lo);
+    N->upper = std::move(up);
+    return RSP_OK;
+}
+
 int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs)
 {
-    if (!N || !S || !B || nrhs < 0 || ldb < N->f.L.n) return RSP_BAD_INPUT;
+    if (!N || !S || !B || nrhs < 0 || ldb < N->f.L.n || S->s.n != N->f.L.n) return RSP_BAD_INPUT;
     return guarded([&] {
         if (int st = require_device()) return st;
+        std::lock_guard<std::mutex> lock(N->guard.m);
         const int64_t n = N->f.L.n;
-        if (!N->lower) {
-            std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
-            if (int st = analyze_pair(*lo, N->f.L.view(), RSP_LSOLVE, *up, N->f.U.view(), RSP_USOLVE, N->single_use)) return st;
-            N->lower = std::move(lo);
-            N->upper = std::move(up);
-        }
+        if (int st = lu_solvers(N)) return st;
         // x = P b (host gather, 16 MB per million unknowns), L and U solves on the GPU, b = Q x
         std::vector<double> x((size_t)n * (size_t)nrhs);
         scatter_rows(n, N->f.pinv.data(), B, x.data(), ldb, nrhs);
@@ -580,6 +748,45 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
         const int64_t *q = S->s.has_q ? S->s.q.data() : nullptr;
         for (int64_t r = 0; r < nrhs; ++r)
             for (int64_t k = 0; k < n; ++k) B[(q ? q[k] : k) + r * ldb] = x[k + r * n];
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_lu_solve_dev_f64(rsp_lu *N, const rsp_symb *S, double *dB, int layout, int64_t ld, int64_t nrhs, void *stream_)
+{
+    if (!N || !S || !dB || nrhs < 0 || nrhs > INT32_MAX || S->s.n != N->f.L.n || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR))
+        return RSP_BAD_INPUT;
+    if (layout == RSP_COL_MAJOR ? ld < N->f.L.n : ld < nrhs) return RSP_BAD_INPUT;
+    if (nrhs == 0 || N->f.L.n == 0) return RSP_OK;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(N->guard.m);
+        hipStream_t stream = (hipStream_t)stream_;
+        const int64_t n = N->f.L.n;
+        if (int st = lu_solvers(N)) return st;
+        if (!N->d_pinv.size()) {
+            N->d_pinv.upload(N->f.pinv);
+            if (S->s.has_q) N->d_q.upload(S->s.q.data(), (size_t)n);
+        }
+        N->guard.begin(stream);
+        // x(pinv[k]) = b[k]  (ipvec, lib.rs:678), into a row-major workspace whatever the caller's layout
+        const int64_t ldw = layout == RSP_COL_MAJOR ? nrhs : ld;
+        N->work.resize((size_t)n * (size_t)ldw);
+        double *W = N->work.get();
+        const dim3 tgrid((unsigned)((n + 31) / 32), (unsigned)((nrhs + 31) / 32)), tblock(256);
+        const dim3 pgrid((unsigned)((n + 3) / 4)), pblock(256);
+        if (layout == RSP_COL_MAJOR)
+            hipLaunchKernelGGL(dev::colmajor_to_rowmajor, tgrid, tblock, 0, stream, dB, ld, W, nrhs, n, (int)nrhs, N->d_pinv.get(), 1);
+        else
+            hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, dB, W, ld, n, (int)nrhs, N->d_pinv.get(), 1);
+        solve_pair_device(*N->lower, *N->upper, W, ldw, nrhs, stream);  // lsolve, usolve (lib.rs:679-680)
+        // b(q[k]) = x[k]  (ipvec with q, lib.rs:681); no q = identity
+        const int64_t *q = S->s.has_q ? N->d_q.get() : nullptr;
+        if (layout == RSP_COL_MAJOR)
+            hipLaunchKernelGGL(dev::rowmajor_to_colmajor, tgrid, tblock, 0, stream, W, nrhs, dB, ld, n, (int)nrhs, q, 1);
+        else
+            hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, W, dB, ld, n, (int)nrhs, q, 1);
+        RSP_HIP(hipGetLastError());
+        N->guard.end(stream);
         return (int)RSP_OK;
     });
 }

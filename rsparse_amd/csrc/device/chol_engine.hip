@@ -708,10 +708,9 @@ void CholFactor::info(i64 *out) const
     out[3] = nlevels_;
     out[4] = (i64)flops_;
     out[5] = annz_ * 12 + lnz_ * 20;  // bytes_chol (upper part of A counted as all given entries)
-    out[6] = lower_ ? lower_->multi_program().nlevels : 0;
-    out[7] = lower_ ? lower_->multi_program().ntasks : 0;
-    out[8] = upper_ ? upper_->multi_program().nlevels : 0;
-    out[9] = upper_ ? upper_->multi_program().ntasks : 0;
+    out[6] = out[7] = out[8] = out[9] = 0;  // zeros until a solve has built the programmes
+    if (lower_) lower_->summary(out[6], out[7]);
+    if (upper_) upper_->summary(out[8], out[9]);
 }
 
 }  // namespace rsp

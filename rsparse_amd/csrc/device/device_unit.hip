@@ -1,4 +1,5 @@
 // Single translation unit for all device code + the C ABI (one code object, no relocatable device linking).
 #include "tri_engine.hip"
 #include "chol_engine.hip"
+#include "spmm_kernels.hip"
 #include "../capi.hip"

@@ -172,6 +172,15 @@ class TriSolver {
     const BlockedProgram &blocked_program() const { return blocked_; }
     const SupernodalProgram &supernodal_program() const { return sn_; }
     bool uses_supernodal() const { return use_sn_; }
+    // kernel launches per sweep and tasks of the programme that has actually been built (zeros before the first solve)
+    void summary(i64 &launches, i64 &tasks) const
+    {
+        if (have_sn_) { launches = sn_.launches; tasks = sn_.nitems + sn_.ntasks; }
+        else if (have_blocked_) { launches = blocked_.launches; tasks = blocked_.ntasks; }
+        else if (have_single_) { launches = single_.nlevels; tasks = single_.ntasks; }
+        else if (have_multi_) { launches = multi_.nlevels; tasks = multi_.ntasks; }
+        else { launches = 0; tasks = 0; }
+    }
     i64 algorithmic_bytes(i64 nrhs) const { return nnz_ * 12 + (n_ + 1) * 4 + 16 * n_ * nrhs; }
     // pieces of the multi-right-hand-side path that solve_pair_device drives on two streams
     void prepare_blocked(i64 total_cols);

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void permute_rows(const double *__restrict__ i
 {
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
-    const int64_t src = scatter ? i : perm[i], dst = scatter ? perm[i] : i;
+    const int64_t p = perm ? perm[i] : i;  // no permutation = identity
+    const int64_t src = scatter ? i : p, dst = scatter ? p : i;
     for (int r = threadIdx.x & 63; r < k; r += 64) out[dst * ld + r] = in[src * ld + r];
 }
 

@@ -12,8 +12,17 @@ namespace rsp {
 
 // worker threads: RSP_HOST_THREADS, else OMP_NUM_THREADS (the GPU boxes set it to their CPU share), else the
 // hardware's count capped at 16
+// (thread-local override: the calling thread's next analyses use exactly this many; 0 = no override.  The self-test uses
+// it instead of touching the process environment, which other threads may be reading.)
+inline int64_t &host_threads_override()
+{
+    static thread_local int64_t value = 0;
+    return value;
+}
+
 inline int64_t host_threads()
 {
+    if (host_threads_override() > 0) return std::min<int64_t>(host_threads_override(), 64);
     for (const char *name : {"RSP_HOST_THREADS", "OMP_NUM_THREADS"})
         if (const char *e = std::getenv(name))
             if (std::atoll(e) > 0) return std::min<int64_t>(std::atoll(e), 64);

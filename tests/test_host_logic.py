@@ -258,3 +258,35 @@ def test_threaded_host_helpers_agree_with_sequential(count, threads):
     """host/parallel.hpp (threaded sort and ranges used by the analyses): same result as the sequential code for any
     thread count, including chunk counts that do not divide the input."""
     assert rs.lib().rsp_selftest_host_threads(count, threads, 12345 + count) == 0
+
+
+def test_symb_from_parts_rejects_corrupt_vectors():
+    """rsp_symb_from_parts: vectors that are later used as indices (cp by chol, q by lu) are validated up front -- where the
+    reference would panic on a bounds check the library returns RSP_BAD_INPUT, never heap corruption."""
+    A = synth.laplacian_2d(6, 5)
+    n = A[0]
+    S = rs.schol(A, 0)
+    pinv, parent, cp = np.array(S.pinv), np.array(S.parent), np.array(S.cp)
+    assert rs.Symb.from_parts(n, pinv=pinv, parent=parent, cp=cp).lnz == S.lnz  # the honest vectors pass
+    bad = []
+    c = cp.copy(); c[0] = 1; bad.append(dict(pinv=pinv, parent=parent, cp=c))                 # does not start at 0
+    c = cp.copy(); c[3] = c[2]; bad.append(dict(pinv=pinv, parent=parent, cp=c))              # an empty column (no diagonal)
+    c = cp.copy(); c[5] = c[4] - 2; bad.append(dict(pinv=pinv, parent=parent, cp=c))          # not monotone
+    c = cp.copy(); c[n] = c[n - 1] + 7; bad.append(dict(pinv=pinv, parent=parent, cp=c))      # last column longer than n - k
+    c = cp.copy(); c[1:] += 10 ** 15; bad.append(dict(pinv=pinv, parent=parent, cp=c))        # absurd sizes
+    p = pinv.copy(); p[2] = p[3]; bad.append(dict(pinv=p, parent=parent, cp=cp))              # not a permutation
+    p = pinv.copy(); p[0] = n; bad.append(dict(pinv=p, parent=parent, cp=cp))                 # out of range
+    q = np.arange(n); q[4] = -1; bad.append(dict(q=q))
+    q = np.arange(n); q[1] = q[2]; bad.append(dict(q=q))
+    t = parent.copy(); t[0] = n; bad.append(dict(pinv=pinv, parent=t, cp=cp))
+    for kw in bad:
+        with pytest.raises(rs.DeviceError, match="status -1"):
+            rs.Symb.from_parts(n, **kw)
+
+
+def test_selftest_leaves_the_environment_alone(monkeypatch):
+    """rsp_selftest_host_threads overrides the thread count for the calling thread only (no setenv in a library call)."""
+    monkeypatch.setenv("RSP_HOST_THREADS", "3")
+    for threads in (1, 2, 5, 0):
+        assert rs.lib().rsp_selftest_host_threads(300000, threads, 7) == 0
+        assert os.environ["RSP_HOST_THREADS"] == "3"
