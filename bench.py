@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the numeric solve path on MI355X (contract: see the task statement / DESIGN.md "Measurement").
 
-Workload (BASELINE.json configs[1], "C2"): 2-D 5-point Laplacian 1024 x 1024 (n = 1 048 576), AMD ordering
+Default workload (BASELINE.json configs[1], "C2"): 2-D 5-point Laplacian 1024 x 1024 (n = 1 048 576), AMD ordering
 (order = 0), Cholesky factor L computed by the GPU numeric Cholesky.  One STEP = lsolve + ltsolve of a block of
 `--nrhs` right-hand sides per GPU (row-major, resident in HBM), i.e. the solve phase of cholsol applied to a
 RHS block.  value = algorithmic GB/s summed over all ranks:
     bytes_step = 2 * (nnz(L) * 12 + (n + 1) * 4 + 16 * n * nrhs)          
 Multi-GPU (one process per GPU, torch.distributed/RCCL): rank 0 factors, the factor is broadcast once
 (untimed set-up), every rank solves its own RHS block -> weak scaling, no collective in the timed region.
+
+Other modes (parity/bench lines of their own, never the headline):
+    --config c3 [--scaling strong]   3-D 7-point Laplacian (default 80^3), 256 right-hand sides; "strong" splits the 256
+                                     columns over the ranks (256 / G each) instead of giving every rank 256
+    --config c5                      batch of 4 096 independent 2 000-unknown SPD systems through rsp_cholsol_batch_f64
+                                     (host arrays in, host arrays out: PCIe inclusive), systems split over the ranks
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (one child process per GPU, rendezvous on
+127.0.0.1) and forwards rank 0's JSON line; under `python -m torch.distributed.run` it takes the ranks it is given and
+refuses to run when --gpus disagrees with WORLD_SIZE.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,29 +33,61 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense f64 matrix-core peak
 
 
 def bytes_trisolve(n, nnz, k):
     return nnz * 12 + (n + 1) * 4 + 16 * n * k
 
 
+def kernels_sha():
+    """Hash of the sources the kernels and programmes are built from: a committed counter profile only speaks for the
+    code it was measured on."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "rsparse_amd", "csrc")
+    for dirpath, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".hpp", ".cpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(dirpath, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(cfg):
     """HBM bytes of one step from the committed rocprofv3 --pmc passes (profiles/*_summary.json, made by
-    tools/pmc.sh + tools/collect_profiles.py on this same command), or None when no pass matches this configuration
-    (same matrix, right-hand sides and programme): counters cannot be read from inside the timed process."""
+    tools/pmc.sh + tools/collect_profiles.py on this same command), with the profile's tag -- or (None, None) when no
+    pass matches this configuration (same matrix, right-hand sides, programme) AND these kernel sources: counters
+    cannot be read from inside the timed process, and a profile of older kernels says nothing about these."""
     import glob
     keys = ("n", "nnz_L", "nrhs_per_gpu", "lsolve_tasks", "lsolve_launches", "ltsolve_launches")
-    best = None
+    best, tag, sha = None, None, kernels_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         t, c = d.get("traffic"), d.get("config", {})
-        if t and all(c.get(k) == cfg.get(k) for k in keys):
-            best = t["hbm_bytes_per_step"]
-    return best
+        if t and d.get("kernels_sha") == sha and all(c.get(k) == cfg.get(k) for k in keys):
+            best, tag = t["hbm_bytes_per_step"], d.get("tag")
+    return best, tag
+
+
+def spawn_ranks(args):
+    """No launcher: start args.gpus child processes of this script, one rank each, and forward rank 0's line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write("".join(ln + "\n" for ln in out0.splitlines() if ln.startswith("{")))  # the line, not a backend's chatter
+    sys.stdout.flush()
+    sys.exit(0 if all(c == 0 for c in codes) else 1)
 
 
 def main():
@@ -50,18 +95,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=("c2", "c3", "c5"), default="c2")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--nrhs", type=int, default=256)
-    ap.add_argument("--grid", type=int, default=1024, help="Laplacian grid side (1024 = the headline configuration)")
-    ap.add_argument("--cpu-rhs", type=int, default=160, help="right-hand sides of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--grid", type=int, default=0, help="Laplacian grid side (default: 1024 for c2 = the headline configuration, 80 for c3)")
+    ap.add_argument("--systems", type=int, default=4096, help="c5: systems in the batch")
+    ap.add_argument("--cpu-rhs", type=int, default=120, help="right-hand sides of the CPU-baseline sample (0 = no CPU baseline)")
+    ap.add_argument("--cpu-chol", type=int, default=1, help="1: the CPU baseline also times schol + chol once (oracle, 1 thread)")
     ap.add_argument("--skip-extras", action="store_true", help="skip the single-RHS cholsol timing")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)  # before anything touches torch or HIP
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to report a line for the wrong size\n")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     # rehearsal hook for a one-GPU box: RSP_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo, so that the whole
     # multi-rank flow (broadcast of the factor, barriers, max over ranks) can be exercised without a second GPU
     rehearsal = os.environ.get("RSP_BENCH_REHEARSAL") == "1"
@@ -79,18 +134,47 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     import rsparse_amd as rs
-    from rsparse_amd import synth
+    from rsparse_amd import sharding, synth
     rs.lib().rsp_set_device(dev.index)
 
-    n = args.grid * args.grid
-    nrhs = args.nrhs
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(t_local):
+        if world == 1:
+            return t_local, [t_local]
+        tt = torch.zeros(world, dtype=torch.float64, device=dev if not rehearsal else "cpu")
+        tt[rank] = t_local
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        dist.barrier()
+        per = [float(v) for v in tt.cpu()]
+        return max(per), per
+
+    if args.config == "c5":
+        bench_batch(args, rank, world, dev, rs, synth, sharding, barrier, max_over_ranks)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    grid = args.grid or (1024 if args.config == "c2" else 80)
+    n = grid * grid if args.config == "c2" else grid ** 3
+    total_rhs = args.nrhs
+    if args.scaling == "strong":
+        col0, nrhs = sharding.column_block(total_rhs, world, rank)
+    else:
+        col0, nrhs = 0, total_rhs
     setup = {}
 
     # ---- set-up (untimed): rank 0 orders, analyses and factors on its GPU ------------------------------------
     extras = {}
+    roofline_chol = None
+    A = None
     if rank == 0:
         t0 = time.time()
-        A = synth.laplacian_2d(args.grid)
+        A = synth.laplacian_2d(grid) if args.config == "c2" else synth.laplacian_3d(grid)
         setup["generate_s"] = time.time() - t0
         t0 = time.time()
         S = rs.schol(A, 0)
@@ -100,6 +184,7 @@ def main():
         setup["chol_analyze_plus_factor_s"] = time.time() - t0
         info = F.info()
         L = F.factor()
+        pinv = np.array(S.pinv)
         # single right-hand side cholsol solve phase (P, lsolve, ltsolve, P'), factor resident
         xstar = 2.0 * synth.splitmix64(1, n) - 1.0
         import scipy.sparse as sp
@@ -126,26 +211,36 @@ def main():
             extras["cholsol_solves_per_s_1rhs"] = 1000.0 / ms
             extras["trisolve_1rhs_GBps"] = 2 * bytes_trisolve(n, info["lnz"], 1) / (ms * 1e-3) / 1e9
             del xb
-            # the literal configs[1]: ONE cholsol call from scratch (ordering, analysis, factorisation, solve, PCIe)
-            xe = b.copy()
-            t0 = time.time()
-            rs.cholsol(A, xe, 0)
-            extras["cholsol_one_shot_s"] = time.time() - t0
-            extras["cholsol_one_shot_x_error"] = float(np.max(np.abs(xe - xstar)) / np.max(np.abs(xstar)))
+            if args.config == "c2":
+                # the literal configs[1]: ONE cholsol call from scratch (ordering, analysis, factorisation, solve, PCIe)
+                xe = b.copy()
+                t0 = time.time()
+                rs.cholsol(A, xe, 0)
+                extras["cholsol_one_shot_s"] = time.time() - t0
+                extras["cholsol_one_shot_x_error"] = float(np.max(np.abs(xe - xstar)) / np.max(np.abs(xstar)))
         fi = F.info()
         extras["chol_factor_ms"] = fi["factor_ms"]
         extras["chol_flops"] = fi["flops"]
         extras["chol_bytes"] = fi["bytes_chol"]
-        extras["chol_GFLOPs"] = fi["flops"] / (fi["factor_ms"] * 1e-3) / 1e9
-        extras["chol_GBps"] = fi["bytes_chol"] / (fi["factor_ms"] * 1e-3) / 1e9
         extras["chol_levels"] = fi["chol_levels"]
         extras["supernodes"] = fi["supernodes"]
+        # the numeric Cholesky against ITS bound: the larger of its algorithmic bytes at HBM speed and its flops at the
+        # dense f64 matrix-core peak (HIP events around the factorisation on the library's stream, rsp_chol_factor_ms)
+        t_hbm = fi["bytes_chol"] / (HBM_PEAK_GBPS * 1e9)
+        t_mfma = fi["flops"] / (MFMA_F64_PEAK_TFLOPS * 1e12)
+        t_meas = fi["factor_ms"] * 1e-3
+        if t_mfma >= t_hbm:
+            roofline_chol = {"bound": "mfma", "achieved": fi["flops"] / t_meas / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        else:
+            roofline_chol = {"bound": "hbm", "achieved": fi["bytes_chol"] / t_meas / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+        roofline_chol.update({"frac": roofline_chol["achieved"] / roofline_chol["peak"], "traffic": None, "ms": fi["factor_ms"],
+                              "bytes": fi["bytes_chol"], "flops": fi["flops"],
+                              "kernel": "chol_panel_factor + chol_tile_update + chol_tiny_panels: one numeric factorisation"})
         del F
         Lp, Li, Lx = L.p, L.i.astype(np.int64), L.x
 
     # ---- the factor travels to the other GPUs once (RCCL broadcast over xGMI), untimed -------------------------
     if world > 1:
-        from rsparse_amd import sharding
         t0 = time.time()
         Lall = sharding.broadcast_factor((n, n, Lp, Li, Lx) if rank == 0 else None, 0, dev, dist)
         _, _, Lp, Li, Lx = Lall
@@ -159,38 +254,46 @@ def main():
     upper = rs.TriHandle(Lt, rs.api.LTSOLVE)
     setup["tri_analyze_s"] = time.time() - t0
 
-    # ---- RHS block of this rank, resident in HBM ---------------------------------------------------------------
-    g = torch.Generator(device=dev)
-    g.manual_seed(2 + rank)
-    X = torch.rand((n, nrhs), dtype=torch.float64, device=dev, generator=g) * 2.0 - 1.0
+    # ---- RHS block of this rank, resident in HBM: SplitMix64 block of seed 2 + rank, mapped to [-1, 1) -----------
+    have = nrhs > 0
+    X = synth.splitmix64_torch(2 + rank, n * max(nrhs, 1), dev, -1.0, 1.0).reshape(n, max(nrhs, 1))
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         # lsolve then ltsolve on the same block; the library pipelines column parts of the block over several streams
-        rs.solve_pair_dev(lower, upper, X.data_ptr(), nrhs, nrhs, stream)
+        if have:
+            rs.solve_pair_dev(lower, upper, X.data_ptr(), nrhs, nrhs, stream)
 
-    # correctness of the timed path itself (rank 0, first column): L L' y = b against scipy's triangular solves
+    # correctness of the timed path itself (rank 0): EVERY column's residual of (P A P') y = b, computed on the device
+    # by rsp_mat_gaxpy_dev_f64 (L L' = P A P': what the solve phase of cholsol inverts), plus L L' y = b on column 0
+    # through scipy's products
     check = {}
-    if rank == 0:
+    if rank == 0 and have:
         import scipy.sparse as sp
-        import scipy.sparse.linalg as spla
-        b0 = X[:, 0].cpu().numpy().copy()
+        B0 = X.clone()
         step()
         torch.cuda.synchronize()
+        Ap = sp.csc_matrix((A[4], (pinv[A[3]], np.repeat(pinv, np.diff(A[2])))), shape=(n, n)).tocsc()
+        Ap.sort_indices()
+        M = rs.MatHandle((n, n, Ap.indptr.astype(np.int64), Ap.indices.astype(np.int64), Ap.data))
+        R = B0.clone()
+        M.gaxpy_dev(X.data_ptr(), nrhs, R.data_ptr(), nrhs, nrhs, rs.api.ROW_MAJOR, -1.0, stream)
+        torch.cuda.synchronize()
+        rel = R.norm(dim=0) / B0.norm(dim=0)
+        check["residual_max_all_columns"] = float(rel.max())
+        check["columns_checked"] = int(nrhs)
+        spread = sorted(set(int(c) for c in np.linspace(0, nrhs - 1, 8)))
+        check["residual_spread_columns"] = {str(c): float(rel[c]) for c in spread}
         y = X[:, 0].cpu().numpy()
+        b0 = B0[:, 0].cpu().numpy()
         Lsp = sp.csc_matrix((Lx, Li, Lp), shape=(n, n))
         r = Lsp @ (Lsp.T @ y) - b0
         check["LLt_residual_col0"] = float(np.linalg.norm(r) / np.linalg.norm(b0))
+        del M, R, B0, rel
     else:
         step()
     for _ in range(max(0, args.warmup - 1)):
         step()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -202,20 +305,17 @@ def main():
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t_start
     ev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-        dist.barrier()
-    else:
-        t_max = t_local
+    t_max, t_per_rank = max_over_ranks(t_local)
 
     if rank == 0:
-        bytes_step = 2 * bytes_trisolve(n, lnz, nrhs)
+        counts = [sharding.column_block(total_rhs, world, r)[1] for r in range(world)] if args.scaling == "strong" else [nrhs] * world
+        bytes_rank = [2 * bytes_trisolve(n, lnz, c) if c else 0 for c in counts]
+        bytes_step = bytes_rank[0]
         ms_per_step = t_max * 1e3 / args.steps
-        value = world * bytes_step / (t_max / args.steps) / 1e9
+        value = sum(bytes_rank) / (t_max / args.steps) / 1e9
         achieved = bytes_step / (ev_ms * 1e-3 / args.steps) / 1e9  # HIP events on the launch stream, this rank
         li, ui = lower.info(), upper.info()
+        name = (f"C2: 2D 5-point Laplacian {grid}x{grid}" if args.config == "c2" else f"C3: 3D 7-point Laplacian {grid}^3")
         out = {
             "metric": "triangular-solve GB/s",
             "value": value,
@@ -225,20 +325,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: 2D 5-point Laplacian {args.grid}x{args.grid}, cholsol(order=0) solve phase "
-                            f"(lsolve+ltsolve) on {nrhs} RHS per GPU, factor from the GPU numeric Cholesky",
+                "workload": f"{name}, cholsol(order=0) solve phase (lsolve+ltsolve) on "
+                            + (f"{total_rhs} RHS split over the GPUs" if args.scaling == "strong" else f"{nrhs} RHS per GPU")
+                            + ", factor from the GPU numeric Cholesky",
                 "n": n, "nnz_L": lnz, "nrhs_per_gpu": nrhs, "rhs_layout": "row-major",
                 "bytes_per_step": bytes_step,
                 "lsolve_launches": li["launches"], "ltsolve_launches": ui["launches"],
                 "lsolve_tasks": li["tasks"], "row_levels": li["row_levels"],
             },
             "pct_hbm_roofline": 100.0 * (value / world) / HBM_PEAK_GBPS,
-            "solves_per_s": world * nrhs / (t_max / args.steps),
+            "solves_per_s": sum(counts) / (t_max / args.steps),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -249,9 +350,22 @@ def main():
             "check": check,
             "extras": extras,
         }
-        out["roofline"]["traffic"] = measured_traffic(out["config"])
+        if world > 1:
+            out["ms_per_step_per_rank"] = [t * 1e3 / args.steps for t in t_per_rank]
+        if args.scaling == "strong":
+            # what a narrower block costs: the coefficients are read once per 64 columns whatever the block's width
+            out["config"]["rhs_total"] = total_rhs
+            out["config"]["columns_per_rank"] = counts
+            out["strong_scaling_note"] = (f"{total_rhs} columns over {world} ranks = {counts[0]} per rank; every rank still reads the whole "
+                                          f"factor ({lnz * 12 / 1e9:.2f} GB per sweep), so efficiency falls as columns per rank fall")
+        traffic, tag = measured_traffic(out["config"])
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_profile"] = tag
+        out["roofline"]["kernels_sha"] = kernels_sha()
+        if roofline_chol is not None:
+            out["roofline_chol"] = roofline_chol
         # ---- CPU baseline: the oracle (C restatement of the reference's loops), 1 thread, same factor -------
-        if args.cpu_rhs > 0 and world == 1:
+        if args.cpu_rhs > 0:
             from oracle import pyoracle as orc
             Lo = orc.lib(native=True)
             s = args.cpu_rhs
@@ -260,15 +374,77 @@ def main():
             Lo.orc_solve_llt_many(n, np.ascontiguousarray(Lp, np.int64), np.ascontiguousarray(Li, np.int64),
                                   np.ascontiguousarray(Lx), Xc, n, s)
             dt = time.perf_counter() - t0
+            try:
+                affinity = len(os.sched_getaffinity(0))
+            except AttributeError:
+                affinity = None
             out["cpu_baseline"] = {
                 "value": 2 * bytes_trisolve(n, lnz, 1) * s / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
                 "sample": f"{s} right-hand sides through lsolve+ltsolve on the same factor ({dt:.1f} s, "
-                          f"oracle/rsparse_oracle.c -O3 -march=native -ffp-contract=off, 1 thread)",
+                          f"oracle/rsparse_oracle.c -O3 -march=native -ffp-contract=off, 1 thread, rank 0 only)",
                 "solves_per_s": s / dt,
+                "nproc": os.cpu_count(), "cpus_allowed": affinity,
             }
+            if args.cpu_chol and A is not None:
+                t0 = time.perf_counter()
+                So = orc.schol(A, 0)
+                t1 = time.perf_counter()
+                st, _ = orc.chol(A, So)
+                t2 = time.perf_counter()
+                out["cpu_baseline"]["schol_s"] = t1 - t0
+                out["cpu_baseline"]["chol_s"] = t2 - t1 if st == orc.OK else None
+                out["cpu_baseline"]["chol_note"] = "oracle schol (ordering + symbolic) and up-looking chol once, 1 thread, same matrix"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_batch(args, rank, world, dev, rs, synth, sharding, barrier, max_over_ranks):
+    """--config c5: 4 096 (or --systems) independent 2 000-unknown SPD systems that share one pattern; every rank takes a
+    contiguous range of systems through rsp_cholsol_batch_f64 (host arrays in and out: the figure is PCIe inclusive)."""
+    n, nsys = 2000, args.systems
+    s0, cnt = sharding.column_block(nsys, world, rank)
+    A0 = synth.circuit_spd(n, 6, 100)
+    nnz = len(A0[4])
+    vals = np.empty((max(cnt, 1), nnz))
+    B = np.empty((max(cnt, 1), n))
+    for k in range(cnt):
+        vals[k] = synth.circuit_spd(n, 6, 100 + s0 + k)[4]
+        B[k] = synth.splitmix64(1000 + s0 + k, n)
+    work = B.copy()
+
+    def step():
+        work[:] = B
+        if cnt:
+            st = rs.cholsol_batch(A0, vals[:cnt], work[:cnt], 0)
+            assert not st.any()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    t_local = time.perf_counter() - t0
+    t_max, per = max_over_ranks(t_local)
+    if rank == 0:
+        import scipy.sparse as sp
+        worst = 0.0
+        for k in range(0, cnt, max(1, cnt // 64)):
+            Asp = sp.csc_matrix((vals[k], A0[3], A0[2]), shape=(n, n))
+            worst = max(worst, float(np.linalg.norm(Asp @ work[k] - B[k]) / np.linalg.norm(B[k])))
+        out = {
+            "metric": "cholsol systems/s (batched)", "value": nsys / (t_max / args.steps), "unit": "systems/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C5: {nsys} independent circuit-style SPD systems of {n} unknowns, one pattern, cholsol(order=0) "
+                                   f"through rsp_cholsol_batch_f64, host arrays (PCIe inclusive), systems split over the GPUs",
+                       "n": n, "systems": nsys, "systems_rank0": cnt, "nnz_A": nnz},
+            "check": {"residual_max_sampled": worst},
+        }
+        if world > 1:
+            out["ms_per_step_per_rank"] = [t * 1e3 / args.steps for t in per]
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -2,8 +2,8 @@
 
 The path shards by INDEPENDENT right-hand-side columns (or independent systems of a batch): every rank holds the whole
 factor and owns a contiguous block of columns, so the solve itself needs no collective.  RCCL (backend "nccl") or gloo
-is used for exactly two things: broadcasting the factor arrays once from the rank that factored, and gathering the
-solution blocks on one rank when the caller wants them there.  No counterpart in the reference (single-threaded CPU).
+is used for exactly two things: broadcasting the factor arrays once from the rank that factored, and sending the
+solution blocks to one rank (point-to-point) when the caller wants them there.  No counterpart in the reference (single-threaded CPU).
 """
 import numpy as np
 
@@ -49,15 +49,22 @@ def gather_columns(local, total, dst, device, dist):
     rank, world = dist.get_rank(), dist.get_world_size()
     n = local.shape[0]
     counts = [column_block(total, world, r)[1] for r in range(world)]
-    width = max(counts) if counts else 0
-    pad = torch.zeros((width, n), dtype=torch.float64, device=device)  # column blocks travel as contiguous rows
-    pad[: local.shape[1]] = torch.as_tensor(np.ascontiguousarray(local.T), device=device)
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    if dist.get_backend() == "nccl":  # no gather primitive on every RCCL build: all_gather, non-roots drop the result
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
-    else:
-        dist.gather(pad, bufs, dst=dst)
+    # column blocks travel as contiguous rows, each straight to `dst` (point-to-point: xGMI links are point-to-point, and
+    # only one rank wants the result -- an all_gather would land total x n doubles on every rank)
+    mine = torch.as_tensor(np.ascontiguousarray(local.T), device=device)
+    bufs = None
+    if rank == dst:
+        bufs = []
+        for r in range(world):
+            if r == dst:
+                bufs.append(mine)
+            else:
+                t = torch.empty((counts[r], n), dtype=torch.float64, device=device)
+                if counts[r]:
+                    dist.recv(t, src=r)
+                bufs.append(t)
+    elif counts[rank]:
+        dist.send(mine, dst=dst)
     if rank != dst:
         return None
     out = np.empty((n, total), dtype=np.float64, order="F")

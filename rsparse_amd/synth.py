@@ -20,6 +20,32 @@ def splitmix64(seed, count):
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
+def splitmix64_torch(seed, count, device, lo=0.0, hi=1.0, chunk=1 << 24):
+    """The same `count` doubles as splitmix64(seed, count), mapped to [lo, hi), generated on `device` as a torch tensor
+    (int64 arithmetic wraps like uint64; logical right shifts are arithmetic shifts with the sign extension masked off),
+    so that a benchmark block of gigabytes never exists on the host."""
+    import torch
+
+    def s64(v):  # a uint64 constant as the int64 with the same bits
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    out = torch.empty(count, dtype=torch.float64, device=device)
+    gamma, m1, m2 = s64(0x9E3779B97F4A7C15), s64(0xBF58476D1CE4E5B9), s64(0x94D049BB133111EB)
+    for start in range(0, count, chunk):
+        stop = min(count, start + chunk)
+        k = torch.arange(start + 1, stop + 1, dtype=torch.int64, device=device)
+        z = k * gamma + s64(seed & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ lsr(z, 30)) * m1
+        z = (z ^ lsr(z, 27)) * m2
+        z = z ^ lsr(z, 31)
+        u = lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+        out[start:stop] = u * (hi - lo) + lo if (lo != 0.0 or hi != 1.0) else u
+    return out
+
+
 def _csc_from_coo(n, rows, cols, vals):
     import scipy.sparse as sp
     A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsc()  # sums duplicates
