@@ -218,6 +218,8 @@ def main():
                 rs.cholsol(A, xe, 0)
                 extras["cholsol_one_shot_s"] = time.time() - t0
                 extras["cholsol_one_shot_x_error"] = float(np.max(np.abs(xe - xstar)) / np.max(np.abs(xstar)))
+        extras["chol_factor_first_call_ms"] = F.info()["factor_ms"]  # includes first-launch costs of every kernel
+        F.refactor(A)  # the figure that is priced: numeric factorisation on the resident analysis (rsp_chol_refactor_f64)
         fi = F.info()
         extras["chol_factor_ms"] = fi["factor_ms"]
         extras["chol_flops"] = fi["flops"]

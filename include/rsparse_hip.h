@@ -168,6 +168,11 @@ int rsp_chol_f64(const rsp_csc_f64 *A, const rsp_symb *S, int64_t *Lp, uint64_t 
 /* factor kept on the device for repeated solves (no reference counterpart; cholsol refactors each call) */
 typedef struct rsp_chol rsp_chol;
 int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F);
+/* New values, same pattern (the loop a time stepper or a Newton iteration runs: the reference calls chol(a, &mut s) again,
+ * lib.rs:278): numeric factorisation alone, on the analysis F already holds.  A must have the pattern F was created
+ * with (only n and nnz are verified).  RSP_NOT_POSITIVE_DEFINITE leaves F without a usable factor until the next
+ * successful call.  Solves after it rebuild the solve programmes' values. */
+int rsp_chol_refactor_f64(rsp_chol *F, const rsp_csc_f64 *A);
 /* B host column-major n x nrhs: B <- A^-1 B through P, lsolve, ltsolve, P' (src/lib.rs:383-386) */
 int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs);
 /* device-resident variant; `permute` = 0 skips P/P' (solves L L' y = b in the permuted ordering) */

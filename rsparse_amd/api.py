@@ -84,6 +84,7 @@ def lib():
             "rsp_amd": (cint, [csc, C.c_int8, vp, C.POINTER(cint)]),
             "rsp_chol_f64": (cint, [csc, vp, vp, vp, vp]),
             "rsp_chol_factor_f64": (cint, [csc, vp, C.POINTER(vp)]),
+            "rsp_chol_refactor_f64": (cint, [vp, csc]),
             "rsp_chol_solve_f64": (cint, [vp, vp, i64, i64]),
             "rsp_chol_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, cint, vp]),
             "rsp_chol_lnz": (i64, [vp]),
@@ -471,6 +472,11 @@ class CholHandle:
         nrhs = 1 if B.ndim == 1 else B.shape[1]
         assert B.dtype == np.float64 and (B.ndim == 1 or B.flags.f_contiguous)
         _check(lib().rsp_chol_solve_f64(self._h, B.ctypes.data, self.n, nrhs))
+
+    def refactor(self, a):
+        """New values on the analysed pattern (chol(a, &mut s) called again, lib.rs:278): numeric factorisation only."""
+        a = _as_sprs(a)
+        _check(lib().rsp_chol_refactor_f64(self._h, C.byref(a._view())))
 
     def solve_dev(self, ptr, layout, ld, nrhs, permute=True, stream=None):
         _check(lib().rsp_chol_solve_dev_f64(self._h, ptr, layout, ld, nrhs, 1 if permute else 0, stream))

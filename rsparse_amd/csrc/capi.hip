@@ -555,6 +555,15 @@ static int chol_factor_impl(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **
 
 int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F) { return chol_factor_impl(A, S, F, false); }
 
+int rsp_chol_refactor_f64(rsp_chol *F, const rsp_csc_f64 *A)
+{
+    if (!F || !sane(A) || A->m != A->n || A->n != F->f.n() || A->p[A->n] != F->f.annz()) return RSP_BAD_INPUT;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(F->guard.m);
+        return F->f.factorize(view_of(A));  // same analysis, same launches; the solve programmes are rebuilt on the next solve
+    });
+}
+
 int rsp_chol_f64(const rsp_csc_f64 *A, const rsp_symb *S, int64_t *Lp, uint64_t *Li, double *Lx)
 {
     if (!Lp || !Li || !Lx) return RSP_BAD_INPUT;

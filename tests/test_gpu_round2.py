@@ -207,6 +207,40 @@ def test_full_size_c5_batch_4096():
         assert st == orc.OK and rel_inf(got[s], want) <= REL_X
 
 
+def test_chol_refactor_twice_vs_oracle():
+    """rsp_chol_refactor_f64: new values on the analysed pattern, factor and solves against the oracle each time."""
+    n = 1500
+    mats = [synth.circuit_spd(n, 6, 100 + s) for s in range(3)]
+    S = rs.schol(mats[0], 0)
+    F = rs.CholHandle(mats[0], S)
+    b = 2.0 * synth.splitmix64(77, n) - 1.0
+    for k, A in enumerate(mats + [mats[0]]):  # back to the first values at the end
+        if k:
+            F.refactor(A)
+        st, Lo = orc.chol(A, orc.schol(A, 0))
+        L = F.factor()
+        assert st == orc.OK and np.array_equal(L.i.astype(np.int64), Lo[3]) and rel_inf(L.x, Lo[4]) <= 1e-11
+        x = b.copy()
+        F.solve(x)
+        st, want = orc.cholsol(A, b.copy(), 0)
+        assert rel_inf(x, want) <= REL_X
+        X = np.asfortranarray(np.stack([b, 2.0 * b, -b], axis=1))
+        F.solve(X)  # the multi-column programme is rebuilt from the new values too
+        assert rel_inf(X[:, 1], 2.0 * want) <= REL_X
+    bad = list(mats[1])
+    bad[4] = bad[4].copy()
+    bad[4][bad[2][17]:bad[2][18]] *= -1.0  # column 17 gets a negative diagonal
+    with pytest.raises(rs.NotPositiveDefinite):
+        F.refactor(tuple(bad))
+    F.refactor(mats[2])  # and the handle recovers
+    x = b.copy()
+    F.solve(x)
+    st, want = orc.cholsol(mats[2], b.copy(), 0)
+    assert rel_inf(x, want) <= REL_X
+    with pytest.raises(rs.DeviceError):
+        F.refactor(synth.circuit_spd(n + 1, 6, 100))  # another size: bad input
+
+
 # ---- device-resident lusol solve -------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("order", [1, -1])
