@@ -4,6 +4,8 @@ The LAST bench step is the span from the (2 x PARTS)-th-to-last solve_clusters l
 column parts (pair pipeline, engine.hpp kPairParts), each with one cluster launch in lsolve (its first) and one in ltsolve
 (its last)."""
 import os, csv, glob, json, os, sys, collections
+sys.path.insert(0, '.')
+from bench import kernels_sha
 
 PARTS = int(os.environ.get("RSP_PAIR_PARTS", "2"))
 
@@ -18,7 +20,7 @@ def last_step(rows, key):
     return rows[idx[-2 * PARTS]:]
 
 
-out = {"tag": tag, "config": bench["config"], "ms_per_step_under_profiler": bench["ms_per_step"],
+out = {"tag": tag, "kernels_sha": kernels_sha(), "config": bench["config"], "ms_per_step_under_profiler": bench["ms_per_step"],
        "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 2 --warmup 1 --cpu-rhs 0 --skip-extras"}
 f = sorted(glob.glob(stats_dir + '/**/*_kernel_stats.csv', recursive=True), key=os.path.getmtime)[-1]
 rows = [r for r in csv.DictReader(open(f)) if 'rsp::dev' in r['Name']]
@@ -31,7 +33,8 @@ last = last_step([r for r in csv.DictReader(open(f)) if ours(r['Kernel_Name'])],
 by = collections.defaultdict(lambda: [0, 0.0])
 for r in last:
     nm = r['Kernel_Name']
-    k = 'solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else 'solve_level<pipelined>' if ', 1>' in nm else 'solve_level<lean>'
+    k = ('solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else
+         'solve_level<deep ring, 16 columns>' if 'true, 1>' in nm else 'solve_level<deep ring, 64 columns>' if 'true, 4>' in nm else 'solve_level<lean>')
     by[k][0] += 1
     by[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 out["step"] = {"launches": len(last),
