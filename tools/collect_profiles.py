@@ -46,9 +46,21 @@ if len(sys.argv) > 5:
         f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
         rs = last_step([r for r in csv.DictReader(open(f)) if r['Counter_Name'] == name and ours(r['Kernel_Name'])], lambda r: int(r['Dispatch_Id']))
         return sum(float(r['Counter_Value']) for r in rs), len(rs)
+    def per_kernel(d, name):
+        f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)[-1]
+        rs = last_step([r for r in csv.DictReader(open(f)) if r['Counter_Name'] == name and ours(r['Kernel_Name'])], lambda r: int(r['Dispatch_Id']))
+        acc = collections.Counter()
+        for r in rs:
+            nm = r['Kernel_Name']
+            k = ('solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else
+                 'solve_level<deep ring, 16 columns>' if 'true, 1>' in nm else 'solve_level<deep ring, 64 columns>' if 'true, 4>' in nm else 'solve_level<lean>')
+            acc[k] += float(r['Counter_Value'])
+        return acc
     (fetch_kb, n1), (write_kb, n2) = total(sys.argv[4], 'FETCH_SIZE'), total(sys.argv[5], 'WRITE_SIZE')
+    pf, pw = per_kernel(sys.argv[4], 'FETCH_SIZE'), per_kernel(sys.argv[5], 'WRITE_SIZE')
     out["traffic"] = {"FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "dispatches": [n1, n2],
                       "hbm_bytes_per_step": int((2 * fetch_kb + write_kb) * 1024),
+                      "per_kernel_GB": {k: {"read_corrected": round(2 * pf[k] * 1024 / 1e9, 2), "write": round(pw[k] * 1024 / 1e9, 2)} for k in pf},
                       "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), summed over the launches of one step; FETCH_SIZE "
                               "doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are counted"}
 json.dump(out, open(f'profiles/{tag}_summary.json', 'w'), indent=1)
