@@ -146,7 +146,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
     // its ancestors when its last panel is done.
     const i64 bp = std::max<i64>(1, env_or("RSP_CHOL_BLOCK_PANELS", kCholBlockPanels));
     // tiny leaf supernodes (chol_tiny_panels): factor and update fused, four panels to a wavefront
-    static const bool use_tiny = !(getenv("RSP_CHOL_TINY") && getenv("RSP_CHOL_TINY")[0] == '0');
+    const bool use_tiny = !(getenv("RSP_CHOL_TINY") && getenv("RSP_CHOL_TINY")[0] == '0');
     // target-owned updates (chol_tile_update): no atomics, bit-reproducible factor
     grouped_ = env_or("RSP_CHOL_GROUPED", kCholGrouped) != 0;
     const bool grouped = grouped_;
@@ -373,14 +373,14 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
         const int32_t dslot = prow[s] > 64 ? (int32_t)ntall_++ : -1;
         panel_rec[s] = dev::CholPanel{Lp_[c0[s]], c0[s + 1] - c0[s], prow[s], dslot, 0};
     }
-    static const i64 fuse_waves = env_or("RSP_CHOL_FUSE_WAVES", kCholFuseWaves);
+    const i64 fuse_waves = env_or("RSP_CHOL_FUSE_WAVES", kCholFuseWaves);
 
     // ---- per level: factor items, row-solve items of the tall panels, update items of the level's panels ------
     levels_.assign(nlevels_, Level{0, 0, 0, 0, 0, 0, 0, 0, false});
     std::vector<int32_t> item_panel, item_block, multi, upd_pair, upd_q;
     std::vector<dev::CholGroup> final_groups;
     size_t next_group = 0;
-    static const bool short_groups = env_or("RSP_CHOL_SHORT_GROUPS", 1) != 0;
+    const bool short_groups = env_or("RSP_CHOL_SHORT_GROUPS", 1) != 0;
     for (i64 l = 0; l < nlevels_; ++l) {
         levels_[l].item_begin = (i64)item_panel.size();
         multi.clear();

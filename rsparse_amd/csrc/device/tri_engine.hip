@@ -460,10 +460,10 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
     const int nchunks = (int)((nrhs + 63) / 64);
     // 16-byte row pieces need aligned rows and whole groups of 4 columns; anything else takes the element-wise path
     const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && lds % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Sw % 16) == 0;
-    static const i64 cluster_cpw = env_or("RSP_CLUSTER_CPW", 2);
-    static const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
-    static const i64 lean_wgs_single = env_or("RSP_LEAN_WGS_SINGLE", kLeanLaunchWorkgroupsSingle);  // one right-hand side
-    static const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);  // tests force the lean launch with 1
+    const i64 cluster_cpw = env_or("RSP_CLUSTER_CPW", 2);
+    const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
+    const i64 lean_wgs_single = env_or("RSP_LEAN_WGS_SINGLE", kLeanLaunchWorkgroupsSingle);  // one right-hand side
+    const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);
     // workgroups of the whole sweep (a proxy for its work), to find the point where the heavy part is over
     i64 total = 0, done = 0;
     if (after_heavy)
@@ -478,7 +478,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
         }
         done += (i64)lv.nclusters * nchunks + ((i64)lv.ntasks[0] * nchunks + 7) / 8;
         if (lv.nclusters && P.dense) {  // dense tasks: one single-wavefront workgroup per (task, 16 * NT columns)
-            static const i64 dense_nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
+            const i64 dense_nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
             const int nt = dense_nt >= 4 ? 4 : dense_nt >= 2 ? 2 : 1;
             const int rb = 16 * nt;
             const int dchunks = (int)((nrhs + rb - 1) / rb);
@@ -529,7 +529,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             // the deep-ring variant, and 16 columns per wavefront instead of 64 so that four times as many compute units
             // share the work.  Many: the lean variant at twice the occupancy.
             const bool pipe = wgs < (unsigned)(nrhs == 1 ? lean_wgs_single : lean_wgs);
-            static const i64 narrow = env_or("RSP_LAT_NARROW", 1);
+            const i64 narrow = env_or("RSP_LAT_NARROW", 1);
             int level_chunks = nchunks;
             const bool nt1 = pipe && narrow && nrhs > 16;
             if (nt1) {
@@ -554,7 +554,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
 void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i64 nrhs, hipStream_t stream)
 {
     if (nrhs <= 0 || first.n() == 0) return;
-    static const bool overlap = !(getenv("RSP_PAIR_OVERLAP") && getenv("RSP_PAIR_OVERLAP")[0] == '0');
+    const bool overlap = !(getenv("RSP_PAIR_OVERLAP") && getenv("RSP_PAIR_OVERLAP")[0] == '0');
     const i64 nchunks = (nrhs + 63) / 64;
     if (!overlap || nchunks < 2) {
         first.solve_device(X, 1, ld, nrhs, stream);
@@ -568,7 +568,7 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X, i64 ld, i
         hipEvent_t start = nullptr, heavy[kMaxParts] = {}, done[kMaxParts] = {};
     };
     static thread_local std::vector<Aux> per_device;
-    static const i64 want_parts = std::max<i64>(2, std::min<i64>(kMaxParts, env_or("RSP_PAIR_PARTS", kPairParts)));
+    const i64 want_parts = std::max<i64>(2, std::min<i64>(kMaxParts, env_or("RSP_PAIR_PARTS", kPairParts)));
     int device = 0;
     RSP_HIP(hipGetDevice(&device));
     if ((size_t)device >= per_device.size()) per_device.resize(device + 1);
@@ -669,12 +669,12 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
     if (nrhs == 1 && (layout == 0 || ld == 1)) {
         // one right-hand side: a column vector is its own row-major n x 1 block.  The blocked programme needs ~170
         // launches per sweep where the plain level programme needs one per dependency level (thousands).
-        static const bool single_levels = getenv("RSP_TRI_SINGLE") && getenv("RSP_TRI_SINGLE")[0] == '1';
+        const bool single_levels = getenv("RSP_TRI_SINGLE") && getenv("RSP_TRI_SINGLE")[0] == '1';
         if (single_levels || single_use_levels_) run_single(dX, stream);
         else run_blocked(dX, 1, 1, stream);
         return;
     }
-    static const bool blocked = !(getenv("RSP_TRI_BLOCKED") && getenv("RSP_TRI_BLOCKED")[0] == '0');
+    const bool blocked = !(getenv("RSP_TRI_BLOCKED") && getenv("RSP_TRI_BLOCKED")[0] == '0');
     auto run = [&](double *X, i64 ldx) { blocked ? run_blocked(X, ldx, nrhs, stream) : run_multi(X, ldx, nrhs, stream); };
     if (layout == 1) {
         run(dX, ld);

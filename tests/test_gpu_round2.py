@@ -331,3 +331,67 @@ def test_shared_handle_on_two_streams():
         torch.cuda.synchronize()
         assert rel_inf(X1.cpu().numpy()[:, [0, 31, 63]], want) <= REL_X
         assert rel_inf(X2.cpu().numpy()[:, [0, 31, 63]], want) <= REL_X
+
+
+# ---- every kernel variant an environment switch selects, against the oracle ------------------------------------------
+
+VARIANTS = [
+    {},                                                   # defaults
+    {"RSP_LEAN_WGS": "1"},                                # every level through the lean variant
+    {"RSP_LEAN_WGS": "1000000"},                          # every level through the deep-ring variant, 16-column wavefronts
+    {"RSP_LEAN_WGS": "1000000", "RSP_LAT_NARROW": "0"},   # ... 64-column wavefronts
+    {"RSP_SMALL_WAVES": "1"},                             # small-block tasks always in their own lean launch
+    {"RSP_SMALL_WAVES": "1000000000"},                    # ... never
+    {"RSP_CLUSTER_CPW": "1"}, {"RSP_CLUSTER_CPW": "4"},   # column chunks of a cluster per workgroup
+    {"RSP_PAIR_OVERLAP": "0"}, {"RSP_PAIR_PARTS": "3"}, {"RSP_PAIR_PARTS": "4"},
+    {"RSP_TRI_BLOCKED": "0"},                             # the plain level programme for blocks of right-hand sides
+    {"RSP_TRI_SINGLE": "1"},                              # ... for one right-hand side
+    {"RSP_SPLIT_SOURCES": "32", "RSP_SPLIT8_SOURCES": "64", "RSP_MAX_BLOCK_SOURCES": "128"},  # more split blocks, partial sums
+    {"RSP_TASK_BLOCKS": "3"},                             # several dependent blocks per wavefront (long unsplit blocks)
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()) or "defaults")
+def test_every_switch_variant_vs_oracle(env, monkeypatch):
+    torch = _torch()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A = synth.laplacian_2d(70, 53)
+    st, L = orc.chol(A, orc.schol(A, 0))
+    B = synth.banded_unsymmetric(2500, band=40)
+    st2, f = orc.lu(B, 1, 1.0)
+    assert st == st2 == orc.OK
+    stream = torch.cuda.current_stream().cuda_stream
+    for T, kinds in ((L, ("lsolve", "ltsolve")), (f["L"], ("lsolve",)), (f["U"], ("usolve", "utsolve"))):
+        n = T[0]
+        for kind in kinds:
+            h = rs.TriHandle(T, {"lsolve": 0, "ltsolve": 1, "usolve": 2, "utsolve": 3}[kind])
+            for nrhs in (1, 4, 8, 16, 20, 128):  # 4..16: aligned blocks narrower than one 16-column chunk ... one 64-column chunk
+                Bh = (2.0 * synth.splitmix64(90 + nrhs, n * nrhs) - 1.0).reshape(n, nrhs)
+                cols = sorted({0, nrhs // 2, nrhs - 1})
+                want = np.stack([orc.trisolve(kind, T, Bh[:, c].copy()) for c in cols], axis=1)
+                X = torch.tensor(Bh, device="cuda:0")
+                h.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, nrhs, nrhs, stream)
+                torch.cuda.synchronize()
+                assert rel_inf(X.cpu().numpy()[:, cols], want) <= REL_X, (kind, nrhs)
+    # the pair entry point (column parts on several streams) on the Cholesky factor
+    n, nrhs = L[0], 192
+    Bh = (2.0 * synth.splitmix64(7, n * nrhs) - 1.0).reshape(n, nrhs)
+    want = np.stack([orc.trisolve("ltsolve", L, orc.trisolve("lsolve", L, Bh[:, c].copy())) for c in (0, 100, 191)], axis=1)
+    lo, up = rs.TriHandle(L, 0), rs.TriHandle(L, 1)
+    X = torch.tensor(Bh, device="cuda:0")
+    rs.solve_pair_dev(lo, up, X.data_ptr(), nrhs, nrhs, stream)
+    torch.cuda.synchronize()
+    assert rel_inf(X.cpu().numpy()[:, [0, 100, 191]], want) <= REL_X
+
+
+@pytest.mark.parametrize("env", [{"RSP_CHOL_GROUPED": "0"}, {"RSP_CHOL_TINY": "0"}, {"RSP_CHOL_FUSE_WAVES": "0"}, {"RSP_CHOL_FUSE_WAVES": "100000"},
+                                 {"RSP_CHOL_SHORT_GROUPS": "0"}, {"RSP_CHOL_BLOCK_PANELS": "1"}],
+                         ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
+def test_every_cholesky_variant_vs_oracle(env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for A in (synth.laplacian_2d(90, 70), synth.laplacian_3d(14), synth.circuit_spd(2500)):
+        st, Lo = orc.chol(A, orc.schol(A, 0))
+        L = rs.CholHandle(A, rs.schol(A, 0)).factor()
+        assert st == orc.OK and np.array_equal(L.i.astype(np.int64), Lo[3]) and rel_inf(L.x, Lo[4]) <= 1e-11
