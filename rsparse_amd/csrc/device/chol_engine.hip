@@ -531,6 +531,15 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
     }
     RSP_HIP(hipEventRecord(ev1, stream));
     RSP_HIP(hipGetLastError());
+#ifdef RSP_CHOL_CLOCKS
+    {
+        unsigned long long clk[8];
+        RSP_HIP(hipMemcpyFromSymbol(clk, HIP_SYMBOL(dev::g_chol_clk), sizeof(clk)));
+        fprintf(stderr, "chol clocks (10 ns ticks) of the last chain-level factor launch:");
+        for (int i = 1; i < 7; ++i) fprintf(stderr, " %lld", (long long)(clk[i] - clk[0]));
+        fprintf(stderr, "\n");
+    }
+#endif
     std::vector<int32_t> status((size_t)nsys);
     RSP_HIP(hipMemcpy(status.data(), d_status.get(), (size_t)nsys * sizeof(int32_t), hipMemcpyDeviceToHost));
     RSP_HIP(hipEventSynchronize(ev1));

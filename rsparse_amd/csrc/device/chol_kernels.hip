@@ -205,18 +205,26 @@ __device__ void chol_unpark_diagonal(const CholUpdateArgs &A, int panel, int lan
 // of a tall panel factors the diagonal block itself, from the unfactored entries in L, and solves its rows.  Nobody
 // may overwrite those entries meanwhile, so wavefront 0 parks the factored block in a side buffer, and the level's
 // update launch copies it into L (chol_rank_update, item_pair < 0).
+#ifdef RSP_CHOL_CLOCKS
+__device__ unsigned long long g_chol_clk[8];
+#define CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nitems >= 6 && nitems <= 8) g_chol_clk[i] = wall_clock64(); } while (0)
+#else
+#define CLK(i)
+#endif
+
 __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64_t item_begin, int64_t nitems, int trsm_only,
                                                          int64_t lx_stride, int64_t dbuf_stride)
 {
     A.Lx += (int64_t)blockIdx.y * lx_stride;
     A.dbuf += (int64_t)blockIdx.y * dbuf_stride;
     A.status += blockIdx.y;  // one status word per system
-    __shared__ double tiles[4][32][33];
+    __shared__ __attribute__((aligned(16))) double tiles[4][32][34];  // rows of 34: 16-byte aligned runs for the row solve
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t it = item_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
     if (it >= item_begin + nitems) return;
-    double(*D)[33] = tiles[wv];
+    double(*D)[34] = tiles[wv];
+    CLK(0);
     const CholFactorItem I = A.items[it];
     const CholPanel P = I.panel;
     const int blk = I.block, w = P.w, r = P.r, len0 = w + r;
@@ -229,24 +237,45 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
 #pragma unroll
     for (int t = 0; t < 32; ++t) x[t] = (solve && t < w) ? A.Lx[panel_entry(P.base, len0, pos, t)] : 0.0;
     if (trsm_only != 1) {
+        CLK(1);
         // dense Cholesky of the diagonal block in registers: lane = row, d[t] = entry (lane, t); the pivot column
         // travels by readlane, so the 32 column steps are straight-line code without a single memory access
         double d[32];
 #pragma unroll
         for (int t = 0; t < 32; ++t) d[t] = (lane < w && t <= lane) ? A.Lx[panel_entry(P.base, len0, lane, t)] : 0.0;
+#ifdef RSP_CHOL_CLOCKS
+        { double sum = 0; for (int t = 0; t < 32; ++t) sum += d[t] + x[t]; if (sum == 1.2345e300) A.status[0] = 1; }
+        CLK(2);
+#endif
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {  // all loads land here: without this fence the compiler interleaves the phases and
+            asm volatile("" : "+v"(d[t]));  // spills 600 registers (measured: 26 ms instead of 11.7 for the factorisation)
+            asm volatile("" : "+v"(x[t]));
+        }
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
             if (t < w) {  // wave-uniform
                 const double dtt = readlane_f64(d[t], t);
                 if (dtt <= 0.0 && lane == 0 && blk <= 0) atomicMin(A.status, I.c0 + t);
-                const double l = sqrt(dtt);
-                const double rl = 1.0 / l;        // L(k,i) = x_i / L(i,i) (lib.rs:310) as a multiplication by the
-                d[t] = lane == t ? l : d[t] * rl;  // reciprocal: one division per column instead of one per entry
+                // 1 / sqrt(d) from the hardware's estimate and two Newton steps, sqrt(d) = d * rsqrt(d) corrected once (full
+                // double precision): the library's sqrt and division are two dependent ~60-instruction sequences per column
+                // on the critical path of the whole factorisation (measured with in-kernel timestamps: 14 of the 27 us of a
+                // chain-level launch were this loop).  L(k,i) = x_i / L(i,i) (lib.rs:310) is a multiplication by rl.
+                double rl = __builtin_amdgcn_rsq(dtt);
+                rl = rl * fma(-0.5 * dtt * rl, rl, 1.5);
+                rl = rl * fma(-0.5 * dtt * rl, rl, 1.5);
+                const double l0 = dtt * rl;
+                const double l = fma(fma(-l0, l0, dtt), 0.5 * rl, l0);
+                d[t] = lane == t ? l : d[t] * rl;
+                if (lane == 0) D[t][t] = rl;  // the row solve multiplies by the reciprocal diagonal
 #pragma unroll
-                for (int jj = t + 1; jj < 32; ++jj)
-                    if (jj < w) d[jj] -= d[t] * readlane_f64(d[t], jj);  // above the diagonal (lane < jj) this collects values nothing reads
+                for (int jj = t + 1; jj < 32; ++jj)  // no test of jj < w: lanes >= w hold zeros, the update is then a no-op
+                    d[jj] -= d[t] * readlane_f64(d[t], jj);  // above the diagonal (lane < jj) this collects values nothing reads
+                // (the pivot column through LDS broadcasts instead of v_readlane: 9.3 us for the 32 columns against 7.1)
             }
         }
+        CLK(3);
+        __builtin_amdgcn_sched_barrier(0);
         const bool parked = trsm_only == 2 && P.dslot >= 0;  // mode 2, tall panel: L keeps the unfactored block for now
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
                 if (!parked) A.Lx[panel_entry(P.base, len0, lane, t)] = d[t];
                 else if (blk == 0) A.dbuf[(int64_t)P.dslot * 1024 + lane * 32 + t] = d[t];
             }
-            if (lane < 32) D[lane][t] = lane == t ? 1.0 / d[t] : d[t];  // the row solve multiplies by the reciprocal diagonal
+            if (lane < 32 && (lane != t || t >= w)) D[t][lane] = d[t];  // TRANSPOSED: D[column][row]; the diagonal already holds its reciprocal
         }
         if (blk < 0) return;
     } else {
@@ -267,25 +296,34 @@ __global__ __launch_bounds__(256) void chol_panel_factor(CholFactorArgs A, int64
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = 64 * k + lane;
-            D[idx & 31][idx >> 5] = ((idx & 31) == (idx >> 5) && (idx >> 5) < w) ? 1.0 / dv[k] : dv[k];
+            D[idx >> 5][idx & 31] = ((idx & 31) == (idx >> 5) && (idx >> 5) < w) ? 1.0 / dv[k] : dv[k];  // D[column][row]
         }
     }
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CLK(4);
 
     if (solve) {
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            if (t < w) {
-                double v = x[t];
+        // by columns (right-looking): once x[u] is final the 31 - u updates it feeds are INDEPENDENT multiply-adds; the
+        // row-wise form is one dependent chain of 496 (measured 4.6 us against 1.x).  No test of u < w: rows and columns
+        // >= w of D are zeros, those x stay zero and are not stored.
+        for (int u = 0; u < 32; ++u) {
+            x[u] *= D[u][u];
 #pragma unroll
-                for (int u = 0; u < t; ++u) v -= x[u] * D[t][u];
-                x[t] = v * D[t][t];
-            }
+            for (int t = u + 1; t < 32; ++t) x[t] -= x[u] * D[u][t];  // a run of one LDS row: 16-byte broadcast reads
         }
+#ifdef RSP_CHOL_CLOCKS
+        { double sum = 0; for (int t = 0; t < 32; ++t) sum += x[t]; if (sum == 1.2345e300) A.status[0] = 1; }
+        CLK(5);
+#endif
+#pragma unroll
+        for (int t = 0; t < 32; ++t) asm volatile("" : "+v"(x[t]));
 #pragma unroll
         for (int t = 0; t < 32; ++t)
             if (t < w) A.Lx[panel_entry(P.base, len0, pos, t)] = x[t];
     }
+    CLK(6);
 }
 
 // ---- rank update, target-owned (atomics-free) --------------------------------------------------------------------
