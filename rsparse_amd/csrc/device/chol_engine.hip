@@ -533,11 +533,11 @@ void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first
     RSP_HIP(hipGetLastError());
 #ifdef RSP_CHOL_CLOCKS
     {
-        unsigned long long clk[8];
+        unsigned long long clk[16];
         RSP_HIP(hipMemcpyFromSymbol(clk, HIP_SYMBOL(dev::g_chol_clk), sizeof(clk)));
         fprintf(stderr, "chol clocks (10 ns ticks) of the last chain-level factor launch:");
         for (int i = 1; i < 7; ++i) fprintf(stderr, " %lld", (long long)(clk[i] - clk[0]));
-        fprintf(stderr, "\n");
+        fprintf(stderr, "  | update: %lld %lld subs %lld\n", (long long)(clk[9] - clk[8]), (long long)(clk[10] - clk[8]), (long long)clk[12]);
     }
 #endif
     std::vector<int32_t> status((size_t)nsys);

@@ -206,7 +206,7 @@ __device__ void chol_unpark_diagonal(const CholUpdateArgs &A, int panel, int lan
 // may overwrite those entries meanwhile, so wavefront 0 parks the factored block in a side buffer, and the level's
 // update launch copies it into L (chol_rank_update, item_pair < 0).
 #ifdef RSP_CHOL_CLOCKS
-__device__ unsigned long long g_chol_clk[8];
+__device__ unsigned long long g_chol_clk[16];
 #define CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && nitems >= 6 && nitems <= 8) g_chol_clk[i] = wall_clock64(); } while (0)
 #else
 #define CLK(i)
@@ -361,6 +361,35 @@ struct CholTileArgs {
     const double *dbuf;
 };
 
+// L(pos, i) -= c for the 8 entries of the tile this lane owns.  All eight loads first, then all eight stores: written as
+// eight `-=` the compiler must assume the stores alias the later loads and serialises eight round trips (measured with
+// in-kernel timestamps: 5 of the 10 us of a chain-level update launch).
+__device__ __forceinline__ void chol_subtract_tile(double *Lx, int64_t tgt_base, int len_s, int w_s, int pos, int g, const f64x4 &c0,
+                                                   const f64x4 &c1)
+{
+    double *p0[4], *p1[4];
+    double v0[4], v1[4];
+    bool ok0[4], ok1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i0 = 4 * s + g, i1 = i0 + 16;
+        ok0[s] = i0 < w_s && i0 <= pos;
+        ok1[s] = i1 < w_s && i1 <= pos;
+        p0[s] = Lx + panel_entry(tgt_base, len_s, pos, ok0[s] ? i0 : 0);  // (pos, 0) always exists: the loads are unconditional
+        p1[s] = Lx + panel_entry(tgt_base, len_s, pos, ok1[s] ? i1 : 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        v0[s] = *p0[s];
+        v1[s] = *p1[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (ok0[s]) *p0[s] = v0[s] - c0[s];
+        if (ok1[s]) *p1[s] = v1[s] - c1[s];
+    }
+}
+
 __global__ __launch_bounds__(256) void chol_tile_update(CholTileArgs A, int64_t group_begin, int64_t ngroups, int64_t lx_stride,
                                                         int64_t dbuf_stride)
 {
@@ -370,6 +399,12 @@ __global__ __launch_bounds__(256) void chol_tile_update(CholTileArgs A, int64_t 
     const int64_t it =
         group_begin + (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (it >= group_begin + ngroups) return;
+#ifdef RSP_CHOL_CLOCKS
+#define CLKU(i) do { if (it == group_begin + ngroups - 1 && lane == 0 && ngroups >= 6 && ngroups <= 40) g_chol_clk[8 + i] = wall_clock64(); } while (0)
+#else
+#define CLKU(i)
+#endif
+    CLKU(0);
     const CholGroup G = A.groups[it];
     if (G.r16 < 0) {  // wave-uniform
         CholUpdateArgs U{nullptr, nullptr, nullptr, nullptr, A.Lx, A.panels, A.dbuf};
@@ -411,14 +446,10 @@ __global__ __launch_bounds__(256) void chol_tile_update(CholTileArgs A, int64_t 
         }
         const int pos = 16 * G.r16 + j;
         if (pos >= G.len_s) return;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int i0 = 4 * s + g, i1 = i0 + 16;
-            if (i0 < w_s && i0 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i0)] -= c0[s];
-            if (i1 < w_s && i1 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i1)] -= c1[s];
-        }
+        chol_subtract_tile(A.Lx, G.tgt_base, G.len_s, w_s, pos, g, c0, c1);
         return;
     }
+    CLKU(1);
     CholSub next = A.subs[G.sub_begin];  // wave-uniform (scalar loads); a group has at least one source range
     for (int k = 0; k < G.sub_count; ++k) {
         const CholSub S = next;
@@ -455,14 +486,14 @@ __global__ __launch_bounds__(256) void chol_tile_update(CholTileArgs A, int64_t 
         }
     }
     // C layout: lane (g, j), register s  <->  panel column 4s + g (+ 16), tile row j
+#ifdef RSP_CHOL_CLOCKS
+    { double sm = c0[0] + c0[1] + c0[2] + c0[3] + c1[0] + c1[1] + c1[2] + c1[3]; if (sm == 1.2345e300) A.Lx[0] = 0; }
+    CLKU(2);
+    if (it == group_begin + ngroups - 1 && lane == 0 && ngroups >= 6 && ngroups <= 40) g_chol_clk[12] = (unsigned long long)G.sub_count;
+#endif
     const int pos = 16 * G.r16 + j;
     if (pos >= G.len_s) return;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int i0 = 4 * s + g, i1 = i0 + 16;
-        if (i0 < G.w_s && i0 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i0)] -= c0[s];
-        if (i1 < G.w_s && i1 <= pos) A.Lx[panel_entry(G.tgt_base, G.len_s, pos, i1)] -= c1[s];
-    }
+    chol_subtract_tile(A.Lx, G.tgt_base, G.len_s, G.w_s, pos, g, c0, c1);
 }
 
 // ---- tiny panels: factor, row solve and update of a whole leaf supernode in a quarter of a wavefront ----------------
