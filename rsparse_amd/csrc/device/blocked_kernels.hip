@@ -21,6 +21,14 @@ namespace dev {
 
 #define RSP_NONE INT32_MIN
 
+#ifdef RSP_TRI_CLOCKS
+// debug aid: phase timestamps (10 ns ticks) of wavefront 0 of workgroup 0 of the class-3 part of a level launch
+__device__ unsigned long long g_tri_clk[16];
+#define TCLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tri_clk[i] = wall_clock64(); } while (0)
+#else
+#define TCLK(i)
+#endif
+
 using BlockHeader = ::rsp::BlockHeader;  // 32 bytes, one s_load_dwordx8 (host/sparse.hpp)
 
 struct BlockArrays {
@@ -542,11 +550,22 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
     PanelCtx c;
     if (valid) {
         constexpr int NL = W == 8 ? 2 : 1;
+        if (W == 8) TCLK(0);
         const Prologue R = load_prologue<NL + 1, NL>(B, rec + (int64_t)w * (NL + 1), lane);  // this wavefront's record of the block
         h = header_of(R);
+        if (W == 8) TCLK(1);
         c = make_ctx<NT>(h, B, X, ldx, S, lds, chunk * 16 * NT, nrhs, lane);
         const int nst = h.nsrc >> 4;
         panel_gather<FAST, LAT, NL, NT>(acc, P, R, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
+#ifdef RSP_TRI_CLOCKS
+        if (W == 8) {
+            double sm = 0;
+            for (int nt = 0; nt < NT; ++nt) sm += acc[nt][0] + acc[nt][1] + acc[nt][2] + acc[nt][3];
+            if (sm == 1.2345e300) X[0] = 0;
+            TCLK(2);
+            if (blockIdx.x == 0 && threadIdx.x == 0) g_tri_clk[8] = (unsigned long long)nst;
+        }
+#endif
         if (w > 0) {
             double *mine = red + (size_t)(w - 1) * 256 * NT + lane;
 #pragma unroll
@@ -556,6 +575,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
         }
     }
     __syncthreads();
+    if (W == 8) TCLK(3);
     if (valid && w == 0) {
         for (int o = 0; o < W - 1; ++o) {
             const double *theirs = red + (size_t)o * 256 * NT + lane;
@@ -565,6 +585,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
                 for (int s = 0; s < 4; ++s) acc[nt][s] += theirs[(nt * 4 + s) * 64];
         }
         panel_finish<FAST, NT>(acc, P, h, c, X, S);
+        if (W == 8) TCLK(4);
     }
 }
 

@@ -541,6 +541,16 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
                                : (nt1 ? dev::solve_level<false, true, 1> : dev::solve_level<false, true, 4>);
             hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, level_chunks);
             done += wgs;
+#ifdef RSP_TRI_CLOCKS
+            if (getenv("RSP_TRI_CLOCKS") && L.wg2 > 0) {
+                RSP_HIP(hipStreamSynchronize(stream));
+                unsigned long long clk[16];
+                RSP_HIP(hipMemcpyFromSymbol(clk, HIP_SYMBOL(dev::g_tri_clk), sizeof(clk)));
+                fprintf(stderr, "level wgs %u (class-3 %d) nt1 %d pipe %d: record %lld gather %lld barrier %lld finish %lld  stages %lld\n", wgs, L.wg2, (int)nt1,
+                        (int)pipe, (long long)(clk[1] - clk[0]), (long long)(clk[2] - clk[0]), (long long)(clk[3] - clk[0]), (long long)(clk[4] - clk[0]),
+                        (long long)clk[8]);
+            }
+#endif
         }
     }
     if (after_heavy && !recorded) RSP_HIP(hipEventRecord(after_heavy, stream));
