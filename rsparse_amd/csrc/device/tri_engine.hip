@@ -531,14 +531,23 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             const bool pipe = wgs < (unsigned)(nrhs == 1 ? lean_wgs_single : lean_wgs);
             const i64 narrow = env_or("RSP_LAT_NARROW", 1);
             int level_chunks = nchunks;
-            const bool nt1 = pipe && narrow && nrhs > 16;
+            const bool nt1 = pipe && narrow && nrhs > 16;  // (blocks of at most 16 columns: see narrow_block below)
             if (nt1) {
                 level_chunks = (int)((nrhs + 15) / 16);
                 wgs = wgs_for(level_chunks);
             }
-            // (the element-wise path has no lean variant: its selects need the registers of the deep-ring one)
-            auto kernel = fast ? (nt1 ? dev::solve_level<true, true, 1> : pipe ? dev::solve_level<true, true, 4> : dev::solve_level<true, false, 4>)
-                               : (nt1 ? dev::solve_level<false, true, 1> : dev::solve_level<false, true, 4>);
+            // Blocks of at most 16 columns (one right-hand side among them) always run 16-column wavefronts (one column
+            // tile: a quarter of the registers), lean on heavy levels.  Wider UNALIGNED blocks (element-wise path) have no
+            // lean variant: their selects need the registers of the deep-ring one.
+            const bool narrow_block = nrhs <= 16;
+            auto kernel = narrow_block ? (fast ? (pipe ? dev::solve_level<true, true, 1> : dev::solve_level<true, false, 1>)
+                                               : (pipe ? dev::solve_level<false, true, 1> : dev::solve_level<false, false, 1>))
+                        : fast ? (nt1 ? dev::solve_level<true, true, 1> : pipe ? dev::solve_level<true, true, 4> : dev::solve_level<true, false, 4>)
+                                       : (nt1 ? dev::solve_level<false, true, 1> : dev::solve_level<false, true, 4>);
+            if (narrow_block && !nt1) {
+                level_chunks = 1;
+                wgs = wgs_for(level_chunks);
+            }
             hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, level_chunks);
             done += wgs;
 #ifdef RSP_TRI_CLOCKS
