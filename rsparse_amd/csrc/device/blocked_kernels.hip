@@ -296,57 +296,18 @@ __device__ __forceinline__ void panel_load_init(f64x4 (&v)[NT], const Prologue &
     }
 }
 
-// ONE right-hand side: nothing but latency counts (a level is a handful of wavefronts waiting for a handful of doubles),
-// and registers are plentiful because only column 0 exists.  All stages of the wavefront (at most DEPTH per batch) are
-// fetched at once -- every id in one round trip, then every row and coefficient in one more -- instead of one
-// dependent gather per stage; only the first column tile is computed.
-template <int DEPTH>
-__device__ __forceinline__ void panel_gather_single(f64x4 &acc0, const PanelCtx &c, int st_begin, int st_end)
-{
-    const bool mine = (c.lane & 15) == 0;  // lanes (g, 0) hold the B operand of column 0
-    for (int s0 = st_begin; s0 < st_end; s0 += DEPTH) {
-        int32_t id[DEPTH][4];
-        double a[DEPTH][4], b[DEPTH][4];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int st = min(s0 + d, st_end - 1);  // clamped: loads stay unconditional
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                id[d][q] = c.sidx[st * 16 + 4 * q + c.g];
-                a[d][q] = c.cf[(int64_t)(st * 16 + 4 * q) * 16 + c.lane];
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[d][q] = mine ? row_ptr(id[d][q], c.X, c.ldx, c.S, c.lds)[0] : 0.0;
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            if (s0 + d < st_end) {  // wave-uniform
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][q], b[d][q], acc0, 0, 0, 0);
-            }
-    }
-}
-
 // acc = coef[st_begin*16 .. st_end*16) * sources - initial rows (the caller negates).  `lead`: this wavefront owns the
 // initial values.  LAT: the latency variant (levels with few workgroups: a deep ring, the triangle fetched up front);
 // otherwise the lean one (4 slots of 4 sources, half the registers, twice the wavefronts per CU, initial rows and
-// triangle fetched at the end).  NL: id lines of the record.
+// triangle fetched at the end).  NL: id lines of the record.  One right-hand side takes the same path (16-column
+// wavefronts, element-wise loads): a special all-stages-at-once gather that fetched its ids from the pool cost one more
+// dependent round trip per block than the record's id lines (2.53 against 2.39 ms per cholsol solve phase at C2).
 template <bool FAST, bool LAT, int NL, int NT>
 __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
 #pragma unroll
     for (int s = 0; s < 4; ++s) P.dest[s] = word_at(R.r0, 8 + 4 * s + c.g);
-    if (!FAST && c.nrhs == 1) {  // wave-uniform
-        panel_load_init<false, NT>(acc, R, c, lead);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = -acc[nt];
-        load_panel_tinv(P, h, c);
-        panel_gather_single<LAT ? 8 : 2>(acc[0], c, st_begin, st_end);
-        return;
-    }
     // K-steps per slot, slots of the ring (NT = 4: 10 registers per K-step; NT = 1: 4)
     constexpr int Q = LAT ? 2 : 1, D = LAT ? 7 : 4;
     constexpr int WIN = 16 * NL;  // K-steps whose ids the record registers hold
