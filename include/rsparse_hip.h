@@ -57,6 +57,10 @@ enum rsp_layout {
 const char *rsp_status_string(int status);
 int rsp_device_count(void);     /* number of visible HIP devices (0 if none) */
 int rsp_set_device(int device); /* device used by the calling thread's later calls */
+/* Devices that the entry points which shard INDEPENDENT work spread it over (now: rsp_cholsol_batch_f64, whose systems go
+ * to the listed devices in contiguous shares, one host thread per device, no exchange between them).  n = 0 restores
+ * the default (the calling thread's current device only); a device listed twice gets two shares.  Process-wide. */
+int rsp_set_devices(const int *ids, int n);
 
 /* ---- one-shot triangular solves, x overwritten in place -------------------------------------
  * rsparse::lsolve / ltsolve / usolve / utsolve (src/lib.rs:464-471, 505-512, 1230-1237, 1271-1278).
@@ -195,7 +199,8 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
  * configuration -- with the ordering and the symbolic analysis done once and every kernel launched once for the
  * whole batch.  status (may be NULL): per system RSP_OK or RSP_NOT_POSITIVE_DEFINITE; such a system keeps its
  * right-hand side, as cholsol returns before touching b.  Returns RSP_OK when the batch ran (with status == NULL:
- * RSP_NOT_POSITIVE_DEFINITE if any system failed). */
+ * RSP_NOT_POSITIVE_DEFINITE if any system failed).  With several devices set by rsp_set_devices the systems are split
+ * over them (north_star: independent batched systems are sharded per GPU). */
 int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B, int64_t nsys, int8_t order, int32_t *status);
 
 /* ---- LU ---------------------------------------------------------------------------------------

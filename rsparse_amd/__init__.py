@@ -32,6 +32,7 @@ from .api import (  # noqa: F401
     lu,
     lusol,
     schol,
+    set_devices,
     solve_pair_dev,
     sqr,
     usolve,

@@ -55,6 +55,7 @@ def lib():
             "rsp_status_string": (C.c_char_p, [cint]),
             "rsp_device_count": (cint, []),
             "rsp_set_device": (cint, [cint]),
+            "rsp_set_devices": (cint, [vp, cint]),
             "rsp_lsolve_f64": (cint, [csc, vp]),
             "rsp_ltsolve_f64": (cint, [csc, vp]),
             "rsp_usolve_f64": (cint, [csc, vp]),
@@ -127,6 +128,12 @@ def _check(status):
 
 def device_count():
     return lib().rsp_device_count()
+
+
+def set_devices(ids):
+    """Devices that cholsol_batch spreads its systems over (empty list: the current device only)."""
+    a = np.ascontiguousarray(ids, np.int32)
+    _check(lib().rsp_set_devices(a.ctypes.data if len(a) else None, len(a)))
 
 
 def _vec(ptr, n, dtype):

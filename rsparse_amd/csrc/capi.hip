@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -641,10 +642,9 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     return st;
 }
 
-int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B, int64_t nsys, int8_t order, int32_t *status)
+// the whole batch on the calling thread's current device
+static int cholsol_batch_on_device(const rsp_csc_f64 *A, const double *Ax_all, double *B, int64_t nsys, int8_t order, int32_t *status)
 {
-    if (!sane_indices(A) || A->m != A->n || nsys < 0 || (nsys > 0 && (!Ax_all || !B))) return RSP_BAD_INPUT;
-    if (nsys == 0 || A->n == 0) return RSP_OK;
     return guarded([&] {
         if (int st = require_device()) return st;
         const int64_t n = A->n, nnz = A->p[n];
@@ -686,6 +686,62 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
         }
         return (!status && any_bad) ? (int)RSP_NOT_POSITIVE_DEFINITE : (int)RSP_OK;
     });
+}
+
+
+// devices the multi-device entry points spread over (rsp_set_devices); empty = the calling thread's current device
+static std::mutex g_devices_guard;
+static std::vector<int> g_devices;
+
+int rsp_set_devices(const int *ids, int n)
+{
+    if (n < 0 || (n > 0 && !ids)) return RSP_BAD_INPUT;
+    const int count = rsp_device_count();
+    for (int k = 0; k < n; ++k)
+        if (ids[k] < 0 || ids[k] >= count) return RSP_BAD_INPUT;
+    std::lock_guard<std::mutex> lock(g_devices_guard);
+    g_devices.assign(ids, ids + n);
+    return RSP_OK;
+}
+
+int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B, int64_t nsys, int8_t order, int32_t *status)
+{
+    if (!sane_indices(A) || A->m != A->n || nsys < 0 || (nsys > 0 && (!Ax_all || !B))) return RSP_BAD_INPUT;
+    if (nsys == 0 || A->n == 0) return RSP_OK;
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lock(g_devices_guard);
+        devs = g_devices;
+    }
+    if (devs.size() <= 1 || nsys < 2 * (int64_t)devs.size()) {
+        if (devs.size() == 1 && hipSetDevice(devs[0]) != hipSuccess) return RSP_DEVICE_ERROR;
+        return cholsol_batch_on_device(A, Ax_all, B, nsys, order, status);
+    }
+    // independent systems: contiguous shares, one host thread per device, no exchange between them (every device
+    // repeats the ordering and the analysis for itself: they depend on the pattern alone and run side by side)
+    const int64_t G = (int64_t)devs.size(), n = A->n, nnz = A->p[n];
+    std::vector<int> rc((size_t)G, RSP_OK);
+    std::vector<int32_t> local;
+    int32_t *st = status;
+    if (!st) {
+        local.assign((size_t)nsys, 0);
+        st = local.data();
+    }
+    std::vector<std::thread> pool;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t lo = nsys * g / G, hi = nsys * (g + 1) / G;
+        pool.emplace_back([&, g, lo, hi] {
+            if (hipSetDevice(devs[g]) != hipSuccess) { rc[g] = RSP_DEVICE_ERROR; return; }
+            rc[g] = cholsol_batch_on_device(A, Ax_all + lo * nnz, B + lo * n, hi - lo, order, st + lo);
+        });
+    }
+    for (auto &t : pool) t.join();
+    for (int64_t g = 0; g < G; ++g)
+        if (rc[g] < 0) return rc[g];
+    if (!status)
+        for (int64_t s = 0; s < nsys; ++s)
+            if (st[s] != RSP_OK) return RSP_NOT_POSITIVE_DEFINITE;
+    return RSP_OK;
 }
 
 // ---- LU -----------------------------------------------------------------------------------------

@@ -395,3 +395,26 @@ def test_every_cholesky_variant_vs_oracle(env, monkeypatch):
         st, Lo = orc.chol(A, orc.schol(A, 0))
         L = rs.CholHandle(A, rs.schol(A, 0)).factor()
         assert st == orc.OK and np.array_equal(L.i.astype(np.int64), Lo[3]) and rel_inf(L.x, Lo[4]) <= 1e-11
+
+
+def test_batch_sharded_over_devices():
+    """rsp_set_devices: the batch's systems go to the listed devices in contiguous shares, one host thread each.  On a
+    one-GPU box the same device is listed twice and three times (two / three shares): same results as one share."""
+    n, nsys = 600, 11
+    mats = [synth.circuit_spd(n, 6, 100 + s) for s in range(nsys)]
+    values = np.ascontiguousarray(np.stack([m[4] for m in mats]))
+    values[7, mats[0][2][5]:mats[0][2][6]] *= -1.0  # system 7 is not positive definite
+    B = np.ascontiguousarray(np.stack([synth.splitmix64(1000 + s, n) for s in range(nsys)]))
+    one = B.copy()
+    st1 = rs.cholsol_batch(mats[0], values, one, 0)
+    assert st1.tolist() == [0] * 7 + [1] + [0] * 3
+    try:
+        for devs in ([0, 0], [0, 0, 0]):
+            rs.set_devices(devs)
+            got = B.copy()
+            st = rs.cholsol_batch(mats[0], values, got, 0)
+            assert st.tolist() == st1.tolist() and np.array_equal(got, one)
+        with pytest.raises(rs.DeviceError):
+            rs.set_devices([0, 99])
+    finally:
+        rs.set_devices([])
