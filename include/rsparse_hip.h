@@ -127,6 +127,14 @@ int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *o
  * Returns RSP_OK when both agree, RSP_BAD_INPUT otherwise. */
 int rsp_selftest_host_threads(int64_t count, int threads, uint64_t seed);
 
+/* ---- binary interchange format of Sprs (beside the reference's text format, Sprs::save / Sprs::load, data.rs:414-516) ----
+ * 32-byte header (magic "RSPSPRS1", m, n, nnz as little-endian int64) followed by p[n+1], i[nnz], x[nnz] as they sit in
+ * memory.  Loading is two calls: the dimensions, then the arrays into caller-allocated storage (validated: monotone p,
+ * indices < m).  RSP_BAD_INPUT for a file that cannot be opened, is truncated, or is not in this format. */
+int rsp_sprs_save_bin(const rsp_csc_f64 *A, const char *path);
+int rsp_sprs_load_bin_dims(const char *path, int64_t *m, int64_t *n, int64_t *nnz);
+int rsp_sprs_load_bin(const char *path, int64_t *p, uint64_t *i, double *x);
+
 /* ---- gaxpy ------------------------------------------------------------------------------------
  * rsparse::gaxpy (src/lib.rs:411-421): r = A x + y for one vector (host pointers; r may alias y). */
 int rsp_gaxpy_f64(const rsp_csc_f64 *A, const double *x, const double *y, double *r);
@@ -183,6 +191,10 @@ int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs);
 int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int64_t nrhs, int permute, void *stream);
 int64_t rsp_chol_lnz(const rsp_chol *F);
 int rsp_chol_get_factor(const rsp_chol *F, int64_t *Lp, uint64_t *Li, double *Lx);
+/* Zero-copy view of the factor where it lives (Nmrc.l without the round trip through host Vecs): the pattern on the
+ * host (Lp: n+1, Li: lnz, exactly the reference's layout), the values ON THE DEVICE (dLx: lnz doubles).  Borrowed: valid
+ * until F is freed or refactored. */
+int rsp_chol_factor_view(const rsp_chol *F, const int64_t **Lp, const uint64_t **Li, const double **dLx);
 /* info[0..9] = n, lnz, supernodes, supernodal levels, flops (sum of squared column counts), algorithmic bytes,
  *              lsolve launches per sweep, lsolve tasks, ltsolve launches per sweep, ltsolve tasks (of the solve
  *              programmes actually built: zeros before the first solve) */

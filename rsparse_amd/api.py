@@ -90,6 +90,10 @@ def lib():
             "rsp_chol_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, cint, vp]),
             "rsp_chol_lnz": (i64, [vp]),
             "rsp_chol_get_factor": (cint, [vp, vp, vp, vp]),
+            "rsp_chol_factor_view": (cint, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+            "rsp_sprs_save_bin": (cint, [csc, C.c_char_p]),
+            "rsp_sprs_load_bin_dims": (cint, [C.c_char_p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+            "rsp_sprs_load_bin": (cint, [C.c_char_p, vp, vp, vp]),
             "rsp_chol_info": (cint, [vp, vp]),
             "rsp_chol_factor_ms": (dbl, [vp]),
             "rsp_chol_free": (None, [vp]),
@@ -171,6 +175,59 @@ class Sprs:
 
     def as_tuple(self):
         return (self.m, self.n, self.p, self.i.astype(np.int64), self.x)
+
+    def save(self, path):
+        """Sprs::save (src/data.rs:414-431): six text lines `nzmax: ..`, `m: ..`, `n: ..`, `p: [..]`, `i: [..]`, `x: [..]`, the
+        vectors in Rust's Debug form (floats in their shortest round-trip decimal, so the values survive exactly)."""
+        def flt(v):
+            r = repr(float(v))
+            if "e" in r:  # Rust prints 1e-7 / 1e16 where Python prints 1e-07 / 1e+16
+                mant, ex = r.split("e")
+                r = mant + "e" + str(int(ex))
+            return r
+        with open(path, "w") as f:
+            f.write(f"nzmax: {self.nzmax}\nm: {self.m}\nn: {self.n}\n")
+            f.write("p: [" + ", ".join(str(int(v)) for v in self.p) + "]\n")
+            f.write("i: [" + ", ".join(str(int(v)) for v in self.i) + "]\n")
+            f.write("x: [" + ", ".join(flt(v) for v in self.x) + "]\n")
+
+    @classmethod
+    def load(cls, path):
+        """Sprs::load (src/data.rs:433-516): parse the six lines Sprs::save writes; like the reference, a file whose nzmax, m
+        or n is 0 yields the empty matrix, and a missing or malformed line is an error (ValueError here)."""
+        fields = {}
+        with open(path) as f:
+            for line in f:
+                key, sep, val = line.partition(":")
+                if sep:
+                    fields[key.strip()] = val.strip()
+        try:
+            nzmax, m, n = int(fields["nzmax"]), int(fields["m"]), int(fields["n"])
+            if nzmax == 0 or m == 0 or n == 0:
+                return cls()
+            vec = lambda key, conv: [conv(t) for t in fields[key].strip("[]").split(",") if t.strip()]
+            p, i, x = vec("p", int), vec("i", int), vec("x", float)
+        except (KeyError, ValueError) as e:
+            raise ValueError(f"{path}: not in the Sprs text format ({e})") from None
+        if len(p) != n + 1 or len(i) != len(x) or p[-1] > len(x):
+            raise ValueError(f"{path}: inconsistent Sprs (n={n}, len(p)={len(p)}, len(i)={len(i)}, len(x)={len(x)})")
+        return cls(m, n, p, i, x)
+
+    def save_bin(self, path):
+        """Binary interchange format (rsp_sprs_save_bin, include/rsparse_hip.h): header + the three arrays as they sit in memory."""
+        _check(lib().rsp_sprs_save_bin(C.byref(self._view()), os.fsencode(path)))
+
+    @classmethod
+    def load_bin(cls, path):
+        """ValueError for a file that is missing, truncated, inconsistent or not in this format (RSP_BAD_INPUT below)."""
+        m, n, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        if lib().rsp_sprs_load_bin_dims(os.fsencode(path), C.byref(m), C.byref(n), C.byref(nnz)) != RSP_OK:
+            raise ValueError(f"{path}: cannot be read as an RSPSPRS1 file")
+        p, i, x = np.zeros(n.value + 1, np.int64), np.zeros(nnz.value, np.uint64), np.zeros(nnz.value)
+        if lib().rsp_sprs_load_bin(os.fsencode(path), p.ctypes.data, i.ctypes.data if nnz.value else None,
+                                   x.ctypes.data if nnz.value else None) != RSP_OK:
+            raise ValueError(f"{path}: truncated or inconsistent RSPSPRS1 file")
+        return cls(m.value, n.value, p, i, x)
 
     def _view(self):
         v = _Csc(self.nzmax, self.m, self.n, self.p.ctypes.data, self.i.ctypes.data, self.x.ctypes.data)
@@ -495,6 +552,15 @@ class CholHandle:
         Lx = np.zeros(max(lnz, 1))
         _check(lib().rsp_chol_get_factor(self._h, Lp.ctypes.data, Li.ctypes.data, Lx.ctypes.data))
         return Sprs(self.n, self.n, Lp, Li[:lnz], Lx[:lnz])
+
+    def factor_view(self):
+        """Zero-copy view of the factor: (Lp, Li) numpy views of the library's host pattern, and the DEVICE address of the lnz
+        values (wrap it with torch / pass it to a kernel).  Borrowed: valid until the handle is freed or refactored."""
+        Lp, Li, dLx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().rsp_chol_factor_view(self._h, C.byref(Lp), C.byref(Li), C.byref(dLx)))
+        lnz = lib().rsp_chol_lnz(self._h)
+        as_np = lambda ptr, cnt, ty, dt: np.frombuffer((ty * cnt).from_address(ptr.value), dtype=dt) if cnt else np.zeros(0, dt)
+        return as_np(Lp, self.n + 1, C.c_int64, np.int64), as_np(Li, lnz, C.c_uint64, np.uint64), dLx.value
 
     def info(self):
         a = np.zeros(10, np.int64)

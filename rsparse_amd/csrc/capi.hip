@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -373,6 +374,75 @@ int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *o
     });
 }
 
+// ---- binary interchange format of Sprs ------------------------------------------------------------
+// 32-byte header: magic "RSPSPRS1", m, n, nnz (int64, little endian), then p[n+1] (int64), i[nnz] (uint64), x[nnz] (f64):
+// the reference's three Vecs as they sit in memory, so a factor of 5e8 entries loads at disk speed instead of being parsed
+// from text (the reference's Sprs::save / Sprs::load, data.rs:414-516, write and parse decimal text).
+namespace {
+constexpr char kSprsMagic[8] = {'R', 'S', 'P', 'S', 'P', 'R', 'S', '1'};
+struct FileCloser {
+    void operator()(FILE *f) const { if (f) fclose(f); }
+};
+}  // namespace
+
+int rsp_sprs_save_bin(const rsp_csc_f64 *A, const char *path)
+{
+    if (!sane(A) || !path) return RSP_BAD_INPUT;
+    return guarded([&] {
+        std::unique_ptr<FILE, FileCloser> f(fopen(path, "wb"));
+        if (!f) return (int)RSP_BAD_INPUT;
+        const int64_t nnz = A->p[A->n], dims[3] = {A->m, A->n, nnz};
+        bool ok = fwrite(kSprsMagic, 1, 8, f.get()) == 8 && fwrite(dims, 8, 3, f.get()) == 3 &&
+                  fwrite(A->p, 8, (size_t)A->n + 1, f.get()) == (size_t)A->n + 1;
+        if (nnz) ok = ok && fwrite(A->i, 8, (size_t)nnz, f.get()) == (size_t)nnz && fwrite(A->x, 8, (size_t)nnz, f.get()) == (size_t)nnz;
+        return ok ? (int)RSP_OK : (int)RSP_BAD_INPUT;
+    });
+}
+
+int rsp_sprs_load_bin_dims(const char *path, int64_t *m, int64_t *n, int64_t *nnz)
+{
+    if (!path || !m || !n || !nnz) return RSP_BAD_INPUT;
+    return guarded([&] {
+        std::unique_ptr<FILE, FileCloser> f(fopen(path, "rb"));
+        char magic[8];
+        int64_t dims[3];
+        if (!f || fread(magic, 1, 8, f.get()) != 8 || std::memcmp(magic, kSprsMagic, 8) != 0 || fread(dims, 8, 3, f.get()) != 3 || dims[0] < 0 ||
+            dims[1] < 0 || dims[2] < 0)
+            return (int)RSP_BAD_INPUT;
+        // the header must account for the file's length exactly, so a corrupt count cannot make the caller allocate wildly
+        if (fseeko(f.get(), 0, SEEK_END) != 0) return (int)RSP_BAD_INPUT;
+        const unsigned long long len = (unsigned long long)ftello(f.get());
+        if (dims[1] > (int64_t)(len / 8) || dims[2] > (int64_t)(len / 16) || len != 32ull + 8ull * (dims[1] + 1) + 16ull * dims[2]) return (int)RSP_BAD_INPUT;
+        *m = dims[0];
+        *n = dims[1];
+        *nnz = dims[2];
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_sprs_load_bin(const char *path, int64_t *p, uint64_t *i, double *x)
+{
+    if (!path || !p) return RSP_BAD_INPUT;
+    return guarded([&] {
+        std::unique_ptr<FILE, FileCloser> f(fopen(path, "rb"));
+        char magic[8];
+        int64_t dims[3];
+        if (!f || fread(magic, 1, 8, f.get()) != 8 || std::memcmp(magic, kSprsMagic, 8) != 0 || fread(dims, 8, 3, f.get()) != 3 || dims[0] < 0 ||
+            dims[1] < 0 || dims[2] < 0)
+            return (int)RSP_BAD_INPUT;
+        const size_t n = (size_t)dims[1], nnz = (size_t)dims[2];
+        if (nnz && (!i || !x)) return (int)RSP_BAD_INPUT;
+        bool ok = fread(p, 8, n + 1, f.get()) == n + 1;
+        if (nnz) ok = ok && fread(i, 8, nnz, f.get()) == nnz && fread(x, 8, nnz, f.get()) == nnz;
+        if (!ok || p[0] != 0 || p[n] != dims[2]) return (int)RSP_BAD_INPUT;  // truncated or inconsistent file
+        for (size_t j = 0; j < n; ++j)
+            if (p[j + 1] < p[j]) return (int)RSP_BAD_INPUT;
+        for (size_t e = 0; e < nnz; ++e)
+            if (i[e] >= (uint64_t)dims[0]) return (int)RSP_BAD_INPUT;
+        return (int)RSP_OK;
+    });
+}
+
 // ---- gaxpy on device-resident blocks ------------------------------------------------------------
 
 int rsp_mat_create_f64(const rsp_csc_f64 *A, rsp_mat **M)
@@ -608,6 +678,15 @@ int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int6
 }
 
 int64_t rsp_chol_lnz(const rsp_chol *F) { return F ? F->f.lnz() : 0; }
+
+int rsp_chol_factor_view(const rsp_chol *F, const int64_t **Lp, const uint64_t **Li, const double **dLx)
+{
+    if (!F || !Lp || !Li || !dLx) return RSP_BAD_INPUT;
+    *Lp = F->f.host_Lp();
+    *Li = reinterpret_cast<const uint64_t *>(F->f.host_Li());
+    *dLx = F->f.device_Lx();
+    return RSP_OK;
+}
 
 int rsp_chol_info(const rsp_chol *F, int64_t *info)
 {

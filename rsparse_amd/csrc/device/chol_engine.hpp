@@ -44,6 +44,10 @@ class CholFactor {
     i64 n() const { return n_; }
     i64 lnz() const { return lnz_; }
     double factor_ms() const { return factor_ms_; }
+    // borrowed views of the factor where it lives: pattern on the host (as the reference stores it), values on the device
+    const i64 *host_Lp() const { return Lp_.data(); }
+    const i64 *host_Li() const { return Li_.data(); }
+    const double *device_Lx() const { return d_Lx.get(); }
     // the factor is solved against once and discarded (cholsol): see TriSolver::set_single_use()
     void set_single_use(bool v) { single_use_ = v; }
 

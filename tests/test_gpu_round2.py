@@ -241,6 +241,36 @@ def test_chol_refactor_twice_vs_oracle():
         F.refactor(synth.circuit_spd(n + 1, 6, 100))  # another size: bad input
 
 
+def test_factor_view_is_the_resident_factor():
+    """rsp_chol_factor_view: the host pattern and the device values the solves read, without a copy; equal to
+    rsp_chol_get_factor's copy, and it follows a refactor."""
+    n = 1200
+    A, A2 = synth.circuit_spd(n, 6, 31), synth.circuit_spd(n, 6, 32)
+    F = rs.CholHandle(A, rs.schol(A, 0))
+    for M in (A, A2):
+        if M is A2:
+            F.refactor(M)
+        L = F.factor()
+        Lp, Li, dLx = F.factor_view()
+        assert np.array_equal(Lp, L.p) and np.array_equal(Li, L.i) and dLx
+        host = np.empty(len(L.x))
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(dLx), ctypes.c_size_t(8 * len(L.x)), 2) == 0  # device to host
+        assert np.array_equal(host, L.x)
+    # the text and binary formats carry the factor exactly
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        L.save(os.path.join(d, "l.sprs"))
+        L.save_bin(os.path.join(d, "l.bin"))
+        for back in (rs.Sprs.load(os.path.join(d, "l.sprs")), rs.Sprs.load_bin(os.path.join(d, "l.bin"))):
+            assert np.array_equal(back.p, L.p) and np.array_equal(back.i, L.i) and np.array_equal(back.x.view(np.uint64), L.x.view(np.uint64))
+            x = 2.0 * synth.splitmix64(5, n) - 1.0
+            want = orc.trisolve("lsolve", L.as_tuple(), x)
+            rs.lsolve(back, x)
+            assert rel_inf(x, want) <= REL_X
+
+
 # ---- device-resident lusol solve -------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("order", [1, -1])

@@ -290,3 +290,76 @@ def test_selftest_leaves_the_environment_alone(monkeypatch):
     for threads in (1, 2, 5, 0):
         assert rs.lib().rsp_selftest_host_threads(300000, threads, 7) == 0
         assert os.environ["RSP_HOST_THREADS"] == "3"
+
+
+# ---- interchange formats (Sprs::save / Sprs::load, data.rs:414-516, and the binary format beside it) ----
+ASSETS = ("cholsol_1.sprs", "cholsol_2.sprs", "cholsol_5.sprs", "cholsol_7.sprs", "lusol_3.sprs", "lusol_4.sprs", "lusol_6.sprs", "qrsol_8.sprs")
+
+
+@pytest.mark.parametrize("name", ASSETS)
+def test_sprs_text_format_reproduces_reference_files(name, tmp_path):
+    """The .sprs assets were written by the reference's Sprs::save: load must read them and save must write them back
+    byte for byte (integer lists and shortest round-trip floats in Rust's Debug form)."""
+    import rsparse_amd as ra
+    src = os.path.join(os.path.dirname(__file__), "golden", "assets", name)
+    A = ra.Sprs.load(src)
+    m, n, p, i, x = load_sprs(name)
+    assert (A.m, A.n) == (m, n) and np.array_equal(A.p, p)
+    nz = int(p[n])
+    assert np.array_equal(A.i[:nz].astype(np.int64), i) and np.array_equal(A.x[:nz], x)
+    out = tmp_path / name
+    A.save(out)
+    assert open(out).read() == open(src).read()
+
+
+def test_sprs_text_format_edge_cases(tmp_path):
+    import rsparse_amd as ra
+    # values whose Python and Rust spellings differ: exponents, negative zero, subnormals
+    x = [1e-7, 1e16, -0.0, 5e-324, 1.5, 123456789.125, 1e21, 1.2345e-10]
+    A = ra.Sprs(8, 1, [0, 8], list(range(8)), x)
+    A.save(tmp_path / "a.sprs")
+    text = open(tmp_path / "a.sprs").read()
+    assert "x: [1e-7, 1e16, -0.0, 5e-324, 1.5, 123456789.125, 1e21, 1.2345e-10]" in text
+    B = ra.Sprs.load(tmp_path / "a.sprs")
+    assert np.array_equal(B.x.view(np.uint64), A.x.view(np.uint64)) and np.array_equal(B.p, A.p) and np.array_equal(B.i, A.i)
+    # the reference returns the empty matrix when nzmax, m or n is 0 (data.rs:445-447)
+    ra.Sprs(3, 3, [0, 0, 0, 0], [], []).save(tmp_path / "z.sprs")
+    Z = ra.Sprs.load(tmp_path / "z.sprs")
+    assert (Z.m, Z.n, Z.nzmax) == (0, 0, 0)
+    with open(tmp_path / "bad.sprs", "w") as f:
+        f.write("nzmax: 2\nm: 2\nn: 2\np: [0, 1, 2]\ni: [0, 1]\n")  # no x line
+    with pytest.raises(ValueError):
+        ra.Sprs.load(tmp_path / "bad.sprs")
+
+
+def test_sprs_binary_format(tmp_path):
+    import rsparse_amd as ra
+    for name in ("cholsol_5.sprs", "lusol_6.sprs"):
+        A = ra.Sprs.from_tuple(load_sprs(name))
+        A.save_bin(tmp_path / "a.bin")
+        B = ra.Sprs.load_bin(tmp_path / "a.bin")
+        assert (B.m, B.n) == (A.m, A.n)
+        assert np.array_equal(B.p, A.p) and np.array_equal(B.i, A.i) and np.array_equal(B.x.view(np.uint64), A.x.view(np.uint64))
+    # the layout the header documents: magic, m, n, nnz, then the three arrays
+    raw = open(tmp_path / "a.bin", "rb").read()
+    assert raw[:8] == b"RSPSPRS1" and np.frombuffer(raw[8:32], np.int64).tolist() == [A.m, A.n, len(A.x)]
+    assert len(raw) == 32 + 8 * (A.n + 1) + 16 * len(A.x)
+    # empty matrix round trip
+    ra.Sprs(0, 0, [0], [], []).save_bin(tmp_path / "e.bin")
+    E = ra.Sprs.load_bin(tmp_path / "e.bin")
+    assert (E.m, E.n, len(E.x)) == (0, 0, 0)
+    # rejected: missing file, wrong magic, truncated, row index out of range
+    with pytest.raises(ValueError):
+        ra.Sprs.load_bin(tmp_path / "nope.bin")
+    open(tmp_path / "m.bin", "wb").write(b"XXXXXXXX" + raw[8:])
+    with pytest.raises(ValueError):
+        ra.Sprs.load_bin(tmp_path / "m.bin")
+    open(tmp_path / "t.bin", "wb").write(raw[:-8])
+    with pytest.raises(ValueError):
+        ra.Sprs.load_bin(tmp_path / "t.bin")
+    bad = bytearray(raw)
+    off = 32 + 8 * (A.n + 1)
+    bad[off:off + 8] = np.uint64(A.m).tobytes()
+    open(tmp_path / "r.bin", "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        ra.Sprs.load_bin(tmp_path / "r.bin")
