@@ -697,7 +697,7 @@ void CholFactor::solve_host(double *B, i64 ldb, i64 nrhs)
 {
     if (nrhs <= 0 || n_ == 0) return;
     DeviceBuffer<double> d((size_t)n_ * (size_t)nrhs);
-    RSP_HIP(hipMemcpy2D(d.get(), n_ * sizeof(double), B, ldb * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyHostToDevice));
+    copy_block_to_device(d.get(), B, n_, ldb, nrhs);
     const bool timing = getenv("RSP_TIMING") != nullptr;
     const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (timing) build_solvers();  // so that the figure below is the solve alone
@@ -706,7 +706,7 @@ void CholFactor::solve_host(double *B, i64 ldb, i64 nrhs)
     solve_device(d.get(), 0, n_, nrhs, true, nullptr);
     RSP_HIP(hipDeviceSynchronize());
     if (timing) fprintf(stderr, "chol solve: %lld right-hand side(s) on the device %.3fs\n", (long long)nrhs, clock() - t0);
-    RSP_HIP(hipMemcpy2D(B, ldb * sizeof(double), d.get(), n_ * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyDeviceToHost));
+    copy_block_to_host(B, d.get(), n_, ldb, nrhs);
 }
 
 void CholFactor::info(i64 *out) const

@@ -25,6 +25,27 @@ struct DeviceError : std::runtime_error {
             throw ::rsp::DeviceError(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
     } while (0)
 
+// An n x nrhs column-major block between host (leading dimension ld_host) and device (packed, leading dimension n): one
+// plain copy when the host block is packed too, else one per column.  Not hipMemcpy2D: under rocprofv3 (kernel trace or
+// counters) its host-to-device form delivered a wrong block on this ROCm (7.2.0; seen as a residual of 4.9 in a
+// one-column solve that is exact outside the profiler).
+inline void copy_block_to_device(double *d, const double *h, i64 n, i64 ld_host, i64 nrhs)
+{
+    if (nrhs == 1 || ld_host == n) {
+        RSP_HIP(hipMemcpy(d, h, (size_t)n * (size_t)nrhs * sizeof(double), hipMemcpyHostToDevice));
+        return;
+    }
+    for (i64 j = 0; j < nrhs; ++j) RSP_HIP(hipMemcpy(d + j * n, h + j * ld_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+}
+inline void copy_block_to_host(double *h, const double *d, i64 n, i64 ld_host, i64 nrhs)
+{
+    if (nrhs == 1 || ld_host == n) {
+        RSP_HIP(hipMemcpy(h, d, (size_t)n * (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost));
+        return;
+    }
+    for (i64 j = 0; j < nrhs; ++j) RSP_HIP(hipMemcpy(h + j * ld_host, d + j * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+}
+
 template <class T>
 class DeviceBuffer {
    public:

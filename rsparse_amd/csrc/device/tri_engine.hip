@@ -714,10 +714,10 @@ void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
 {
     if (nrhs <= 0 || n_ == 0) return;
     DeviceBuffer<double> d((size_t)n_ * (size_t)nrhs);
-    RSP_HIP(hipMemcpy2D(d.get(), n_ * sizeof(double), X, ldx * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyHostToDevice));
+    copy_block_to_device(d.get(), X, n_, ldx, nrhs);
     solve_device(d.get(), 0, n_, nrhs, nullptr);
     RSP_HIP(hipDeviceSynchronize());
-    RSP_HIP(hipMemcpy2D(X, ldx * sizeof(double), d.get(), n_ * sizeof(double), n_ * sizeof(double), nrhs, hipMemcpyDeviceToHost));
+    copy_block_to_host(X, d.get(), n_, ldx, nrhs);
 }
 
 }  // namespace rsp

@@ -271,6 +271,32 @@ def test_factor_view_is_the_resident_factor():
             assert rel_inf(x, want) <= REL_X
 
 
+def test_host_blocks_with_a_leading_dimension_vs_oracle():
+    """rsp_chol_solve_f64 / rsp_tri_solve_f64 on host blocks whose leading dimension exceeds n (the C ABI's ldb / ldx):
+    every column against the oracle, the rows between the columns untouched."""
+    n, k, pad = 900, 3, 7
+    A = synth.circuit_spd(n, 6, 41)
+    F = rs.CholHandle(A, rs.schol(A, 0))
+    cols = [2.0 * synth.splitmix64(50 + j, n) - 1.0 for j in range(k)]
+    big = np.full((n + pad, k), 123.0, order="F")
+    for j in range(k):
+        big[:n, j] = cols[j]
+    rs.api._check(rs.api.lib().rsp_chol_solve_f64(F._h, big.ctypes.data, n + pad, k))
+    assert np.all(big[n:] == 123.0)
+    for j in range(k):
+        st, want = orc.cholsol(A, cols[j].copy(), 0)
+        assert st == orc.OK and rel_inf(big[:n, j], want) <= REL_X
+    L = F.factor()
+    T = rs.TriHandle(L, rs.api.LSOLVE)
+    big = np.full((n + pad, k), -7.0, order="F")
+    for j in range(k):
+        big[:n, j] = cols[j]
+    rs.api._check(rs.api.lib().rsp_tri_solve_f64(T._h, big.ctypes.data, n + pad, k))
+    assert np.all(big[n:] == -7.0)
+    for j in range(k):
+        assert rel_inf(big[:n, j], orc.trisolve("lsolve", L.as_tuple(), cols[j])) <= REL_X
+
+
 # ---- device-resident lusol solve -------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("order", [1, -1])
