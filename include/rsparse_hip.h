@@ -155,6 +155,10 @@ void rsp_mat_free(rsp_mat *M);
 typedef struct rsp_symb rsp_symb;
 int rsp_schol(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
 int rsp_sqr_lu(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
+/* sqr(a, order, qr = true) (src/lib.rs:1114-1133): q = amd(order) on A'A, parent = column elimination tree, cp = the n
+ * row counts of R, pinv = the 2m + n entries vcount returns (row permutation, n zeros, leftmost), m2, lnz = nnz(V),
+ * unz = nnz(R).  A may be rectangular (m >= n for a factorisation; qrsol transposes otherwise). */
+int rsp_sqr_qr(const rsp_csc_f64 *A, int8_t order, rsp_symb **S);
 /* build a Symb from caller-held vectors (pinv/q may be NULL = None) -- for chol(a, &mut s) with any s.
  * RSP_BAD_INPUT unless pinv and q are permutations of 0..n-1, parent[k] is -1 or < n, cp[0] == 0 and every column of
  * cp holds 1..n-k entries (the reference would panic on a bounds check where these are used as indices). */
@@ -167,6 +171,9 @@ const int64_t *rsp_symb_parent(const rsp_symb *S); /* n entries (schol only) */
 const int64_t *rsp_symb_cp(const rsp_symb *S);     /* n+1 entries (schol only) */
 int64_t rsp_symb_lnz(const rsp_symb *S);
 int64_t rsp_symb_unz(const rsp_symb *S);
+int64_t rsp_symb_m2(const rsp_symb *S);       /* sqr_qr only: rows of V and R (m plus fictitious rows) */
+int64_t rsp_symb_pinv_len(const rsp_symb *S); /* n (schol), 2m + n (sqr_qr), 0 for None */
+int64_t rsp_symb_cp_len(const rsp_symb *S);   /* n + 1 (schol), n (sqr_qr), 0 (sqr_lu) */
 void rsp_symb_free(rsp_symb *S);
 /* the ordering alone: rsparse's private amd (src/lib.rs:1292-1752). Returns RSP_OK and *has_perm = 0
  * for the natural ordering (order < 0), else writes n+1 entries to P. */
@@ -185,6 +192,13 @@ int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F);
  * with (only n and nnz are verified).  RSP_NOT_POSITIVE_DEFINITE leaves F without a usable factor until the next
  * successful call.  Solves after it rebuild the solve programmes' values. */
 int rsp_chol_refactor_f64(rsp_chol *F, const rsp_csc_f64 *A);
+/* Iterative refinement of an already solved block, entirely on the device (no reference counterpart: the
+ * reference solves once): `steps` times  W = A X - B (rsp_mat_gaxpy_dev_f64),  W = A^-1 W with the resident factor (the
+ * cholsol solve phase, lib.rs:383-386),  X = X - W.  dB, dX, dW: three distinct n x nrhs device blocks of the same
+ * layout and leading dimension; dB is read only, dW is scratch.  M: the matrix A that F factors (rsp_mat_create_f64).
+ * Asynchronous on `stream`. */
+int rsp_chol_refine_dev_f64(rsp_chol *F, const rsp_mat *M, const double *dB, double *dX, double *dW, int layout, int64_t ld, int64_t nrhs,
+                            int steps, void *stream);
 /* B host column-major n x nrhs: B <- A^-1 B through P, lsolve, ltsolve, P' (src/lib.rs:383-386) */
 int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs);
 /* device-resident variant; `permute` = 0 skips P/P' (solves L L' y = b in the permuted ordering) */
@@ -230,6 +244,25 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
 int rsp_lu_solve_dev_f64(rsp_lu *N, const rsp_symb *S, double *dB, int layout, int64_t ld, int64_t nrhs, void *stream);
 void rsp_lu_free(rsp_lu *N);
 int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol);
+
+/* ---- QR: the consumer of usolve / utsolve --------------------------------------------------------
+ * rsparse::qr (src/lib.rs:788-877): Householder QR on the host (like lu: sequential, order of operations kept), Nmrc.l = V
+ * (diagonal first in every column), Nmrc.u = R (m2 x n, diagonal last), Nmrc.b = beta; borrowed views as for rsp_lu.
+ * rsp_qr_solve_f64 is the solve phase of rsparse::qrsol (src/lib.rs:931-955) with the triangular solve on the GPU:
+ *   transposed == 0 (the handle factors A, m >= n): b[0, m) in, least-squares solution in b[0, n)
+ *       ipvec(pinv), happly k = 0 .. n-1, usolve(R), ipvec(q)                         (lib.rs:936-942)
+ *   transposed == 1 (the handle factors A' of an underdetermined A): b[0, rows of A) in, minimum-norm solution in
+ *       b[0, columns of A):  pvec(q), utsolve(R), happly k = n-1 .. 0, pvec(pinv)     (lib.rs:949-954)
+ * rsp_qrsol_f64 = rsparse::qrsol (src/lib.rs:927-956): b holds max(m, n) entries; no error variants (the reference
+ * returns ()), negative codes only. */
+typedef struct rsp_qr rsp_qr;
+int rsp_qr_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_qr **N);
+int rsp_qr_V(const rsp_qr *N, rsp_csc_f64 *V);
+int rsp_qr_R(const rsp_qr *N, rsp_csc_f64 *R);
+const double *rsp_qr_beta(const rsp_qr *N); /* n entries */
+int rsp_qr_solve_f64(rsp_qr *N, const rsp_symb *S, double *b, int transposed);
+void rsp_qr_free(rsp_qr *N);
+int rsp_qrsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
 
 #ifdef __cplusplus
 }

@@ -161,3 +161,55 @@ def sqr_qr(A, order, numeric=True):
                          Rp.ctypes.data, Ri.ctypes.data, Rx.ctypes.data, beta.ctypes.data)
         out.update(Vp=Vp, Vi=Vi, Vx=Vx, Rp=Rp, Ri=Ri, Rx=Rx, beta=beta)
     return out
+
+
+def _transpose(A):
+    """transpose (lib.rs:1178-1200): rows of every column of the result ascend."""
+    m, n, p, i, x = _csc(A)
+    nz = int(p[n])
+    cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(p))
+    order = np.argsort(i[:nz], kind="stable")
+    tp = np.zeros(m + 1, np.int64)
+    np.add.at(tp, i[:nz] + 1, 1)
+    return (n, m, np.cumsum(tp), cols[order], x[:nz][order])
+
+
+def _happly(f, k, x):
+    """happly (lib.rs:2099-2111) with column k of V: sums in entry order, one product and one add at a time."""
+    lo, hi = int(f["Vp"][k]), int(f["Vp"][k + 1])
+    rows, v = f["Vi"][lo:hi], f["Vx"][lo:hi]
+    tau = 0.0
+    for e in range(hi - lo):
+        tau += v[e] * x[rows[e]]
+    tau *= f["beta"][k]
+    for e in range(hi - lo):
+        x[rows[e]] -= v[e] * tau
+
+
+def qrsol(A, b, order):
+    """qrsol (lib.rs:927-956) from the oracle's sqr + qr (orc_sqr_qr), happly above and orc_usolve / orc_utsolve.
+    b holds max(m, n) entries; returns the overwritten copy."""
+    m, n, p, i, x = _csc(A)
+    b = np.array(b, dtype=np.float64)
+    if m >= n:
+        f = sqr_qr(A, order, numeric=True)
+        R = (n, n, f["Rp"], f["Ri"], f["Rx"])
+        w = np.zeros(f["m2"])
+        w[f["pinv"][:m]] = b[:m]                                  # ipvec(m, pinv, b, x)
+        for k in range(n):
+            _happly(f, k, w)
+        w[:n] = trisolve("usolve", R, w[:n])
+        q = f["q"][:n] if f["q"] is not None else np.arange(n)
+        b[q] = w[:n]                                              # ipvec(n, q, x, b)
+    else:
+        At = _transpose(A)
+        f = sqr_qr(At, order, numeric=True)                       # At is n x m
+        R = (m, m, f["Rp"], f["Ri"], f["Rx"])
+        w = np.zeros(f["m2"])
+        q = f["q"][:m] if f["q"] is not None else np.arange(m)
+        w[:m] = b[q]                                              # pvec(m, q, b, x)
+        w[:m] = trisolve("utsolve", R, w[:m])
+        for k in range(m - 1, -1, -1):
+            _happly(f, k, w)
+        b[:n] = w[f["pinv"][:n]]                                  # pvec(n, pinv, x, b)
+    return b

@@ -31,6 +31,10 @@ from .api import (  # noqa: F401
     ltsolve,
     lu,
     lusol,
+    qr,
+    qrsol,
+    transpose,
+    QrHandle,
     schol,
     set_devices,
     solve_pair_dev,

@@ -72,6 +72,17 @@ def lib():
             "rsp_tri_validate_supernodal": (cint, [csc, cint, vp, vp, vp]),
             "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
+            "rsp_sqr_qr": (cint, [csc, C.c_int8, C.POINTER(vp)]),
+            "rsp_symb_m2": (i64, [vp]),
+            "rsp_symb_pinv_len": (i64, [vp]),
+            "rsp_symb_cp_len": (i64, [vp]),
+            "rsp_qr_f64": (cint, [csc, vp, C.POINTER(vp)]),
+            "rsp_qr_V": (cint, [vp, csc]),
+            "rsp_qr_R": (cint, [vp, csc]),
+            "rsp_qr_beta": (vp, [vp]),
+            "rsp_qr_solve_f64": (cint, [vp, vp, vp, cint]),
+            "rsp_qr_free": (None, [vp]),
+            "rsp_qrsol_f64": (cint, [csc, vp, C.c_int8]),
             "rsp_sqr_lu": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_symb_from_parts": (cint, [i64, vp, vp, vp, vp, C.POINTER(vp)]),
             "rsp_symb_n": (i64, [vp]),
@@ -86,6 +97,7 @@ def lib():
             "rsp_chol_f64": (cint, [csc, vp, vp, vp, vp]),
             "rsp_chol_factor_f64": (cint, [csc, vp, C.POINTER(vp)]),
             "rsp_chol_refactor_f64": (cint, [vp, csc]),
+            "rsp_chol_refine_dev_f64": (cint, [vp, vp, vp, vp, vp, cint, i64, i64, cint, vp]),
             "rsp_chol_solve_f64": (cint, [vp, vp, i64, i64]),
             "rsp_chol_solve_dev_f64": (cint, [vp, vp, cint, i64, i64, cint, vp]),
             "rsp_chol_lnz": (i64, [vp]),
@@ -273,12 +285,13 @@ class Symb:
         self._h = C.c_void_p(handle)
         L = lib()
         self.n = L.rsp_symb_n(self._h)
-        self.pinv = _vec(L.rsp_symb_pinv(self._h), self.n, np.int64)
+        self.pinv = _vec(L.rsp_symb_pinv(self._h), L.rsp_symb_pinv_len(self._h), np.int64)  # n (schol) or 2m + n (sqr, qr)
         self.q = _vec(L.rsp_symb_q(self._h), self.n + 1, np.int64)
         self.parent = _vec(L.rsp_symb_parent(self._h), self.n, np.int64)
-        self.cp = _vec(L.rsp_symb_cp(self._h), self.n + 1, np.int64)
+        self.cp = _vec(L.rsp_symb_cp(self._h), L.rsp_symb_cp_len(self._h), np.int64)  # n + 1 (schol) or n (sqr, qr)
         self.lnz = L.rsp_symb_lnz(self._h)
         self.unz = L.rsp_symb_unz(self._h)
+        self.m2 = L.rsp_symb_m2(self._h)
 
     @classmethod
     def from_parts(cls, n, pinv=None, q=None, parent=None, cp=None):
@@ -307,12 +320,10 @@ def schol(a, order):
 
 
 def sqr(a, order, qr=False):
-    """rsparse::sqr (src/lib.rs:1114), LU branch only (qr=true is outside the accelerated path)."""
-    if qr:
-        raise NotImplementedError("QR symbolic analysis is outside the numeric solve path (SURVEY.md section 8)")
+    """rsparse::sqr (src/lib.rs:1114): ordering and symbolic analysis for LU (qr=False) or QR (qr=True), on the host."""
     a = _as_sprs(a)
     h = C.c_void_p()
-    _check(lib().rsp_sqr_lu(C.byref(a._view()), order, C.byref(h)))
+    _check((lib().rsp_sqr_qr if qr else lib().rsp_sqr_lu)(C.byref(a._view()), order, C.byref(h)))
     return Symb(h.value)
 
 
@@ -446,6 +457,66 @@ class MatHandle:
             self._h = None
 
 
+class QrHandle:
+    """rsparse::data::Nmrc of a QR factorisation (.l = V, .u = R, .b = beta), owned by the library."""
+
+    def __init__(self, handle, symb):
+        self._h = C.c_void_p(handle)
+        self._s = symb
+
+    _mat = LuHandle._mat
+
+    @property
+    def l(self):
+        return self._mat(lib().rsp_qr_V)
+
+    @property
+    def u(self):
+        return self._mat(lib().rsp_qr_R)
+
+    @property
+    def b(self):
+        return _vec(lib().rsp_qr_beta(self._h), self._s.n, np.float64)
+
+    def solve(self, b, transposed=False):
+        """The solve phase of qrsol (src/lib.rs:936-942, or :949-954 when the handle factors the transpose); b is overwritten."""
+        assert b.dtype == np.float64 and b.flags.c_contiguous and b.ndim == 1
+        _check(lib().rsp_qr_solve_f64(self._h, self._s._h, b.ctypes.data, 1 if transposed else 0))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.rsp_qr_free(self._h)
+            self._h = None
+
+
+def qr(a, s):
+    """rsparse::qr (src/lib.rs:788): Householder QR on the host; returns a handle with .l (V), .u (R), .b (beta)."""
+    a = _as_sprs(a)
+    h = C.c_void_p()
+    _check(lib().rsp_qr_f64(C.byref(a._view()), s._h, C.byref(h)))
+    return QrHandle(h.value, s)
+
+
+def qrsol(a, b, order):
+    """rsparse::qrsol (src/lib.rs:927): least-squares (m >= n) or minimum-norm (m < n) solution in b, which holds
+    max(m, n) entries; the triangular solve with R runs on the GPU."""
+    a = _as_sprs(a)
+    assert b.dtype == np.float64 and b.flags.c_contiguous and b.shape == (max(a.m, a.n),)
+    _check(lib().rsp_qrsol_f64(C.byref(a._view()), b.ctypes.data, order))
+
+
+def transpose(a):
+    """rsparse::transpose (src/lib.rs:1178): host-side helper of the test-suite."""
+    a = _as_sprs(a)
+    nz = int(a.p[a.n])
+    p = np.zeros(a.m + 1, np.int64)
+    np.add.at(p, a.i[:nz].astype(np.int64) + 1, 1)
+    p = np.cumsum(p)
+    cols = np.repeat(np.arange(a.n), np.diff(a.p))
+    order = np.argsort(a.i[:nz].astype(np.int64), kind="stable")
+    return Sprs(a.n, a.m, p, cols[order], a.x[:nz][order])
+
+
 def lusol(a, b, order, tol):
     """rsparse::lusol (src/lib.rs:672): b <- A^-1 b."""
     a = _as_sprs(a)
@@ -552,6 +623,11 @@ class CholHandle:
         Lx = np.zeros(max(lnz, 1))
         _check(lib().rsp_chol_get_factor(self._h, Lp.ctypes.data, Li.ctypes.data, Lx.ctypes.data))
         return Sprs(self.n, self.n, Lp, Li[:lnz], Lx[:lnz])
+
+    def refine_dev(self, mat, b_ptr, x_ptr, w_ptr, layout, ld, nrhs, steps=1, stream=None):
+        """`steps` rounds of iterative refinement of the solved block at x_ptr (right-hand sides at b_ptr, scratch at
+        w_ptr; device addresses, one layout and leading dimension), asynchronous on `stream`."""
+        _check(lib().rsp_chol_refine_dev_f64(self._h, mat._h, b_ptr, x_ptr, w_ptr, layout, ld, nrhs, steps, stream))
 
     def factor_view(self):
         """Zero-copy view of the factor: (Lp, Li) numpy views of the library's host pattern, and the DEVICE address of the lnz

@@ -73,6 +73,13 @@ struct rsp_lu {
     UseGuard guard;
 };
 
+struct rsp_qr {
+    QrFactors f;
+    int64_t m = 0, n = 0;                // of the matrix that was factored
+    std::unique_ptr<TriSolver> upper[2];  // usolve / utsolve with R, built on first use
+    UseGuard guard;
+};
+
 namespace {
 
 CscView view_of(const rsp_csc_f64 *A)
@@ -502,6 +509,35 @@ int rsp_mat_gaxpy_dev_f64(const rsp_mat *M, const double *dX, int64_t ldx, doubl
     });
 }
 
+// Iterative refinement of a solved block, all on the device: per step  W = A X - B,  W = A^-1 W (the resident factor:
+// P, lsolve, ltsolve, P' of cholsol, lib.rs:383-386),  X = X - W.
+int rsp_chol_refine_dev_f64(rsp_chol *F, const rsp_mat *M, const double *dB, double *dX, double *dW, int layout, int64_t ld, int64_t nrhs,
+                            int steps, void *stream)
+{
+    if (!F || !M || !dB || !dX || !dW || nrhs < 0 || nrhs > INT32_MAX || steps < 0 || (layout != RSP_COL_MAJOR && layout != RSP_ROW_MAJOR))
+        return RSP_BAD_INPUT;
+    const int64_t n = F->f.n();
+    if (M->m != n || M->n != n || (layout == RSP_COL_MAJOR ? ld < n : ld < nrhs)) return RSP_BAD_INPUT;
+    if (dW == dX || dW == dB || dX == dB) return RSP_BAD_INPUT;
+    if (nrhs == 0 || n == 0) return RSP_OK;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(F->guard.m);
+        hipStream_t st = (hipStream_t)stream;
+        F->guard.begin(st);
+        const int64_t rows = layout == RSP_ROW_MAJOR ? n : nrhs, cols = layout == RSP_ROW_MAJOR ? nrhs : n;
+        const unsigned grid = (unsigned)std::min<int64_t>((rows * cols + 255) / 256, 1 << 16);
+        for (int s = 0; s < steps; ++s) {
+            hipLaunchKernelGGL(dev::block_axpby, dim3(grid), dim3(256), 0, st, dW, ld, dB, ld, rows, cols, 1.0, 0.0);
+            if (int e = rsp_mat_gaxpy_dev_f64(M, dX, ld, dW, ld, nrhs, layout, -1.0, stream)) return e;
+            F->f.solve_device(dW, layout, ld, nrhs, true, st);
+            hipLaunchKernelGGL(dev::block_axpby, dim3(grid), dim3(256), 0, st, dX, ld, dW, ld, rows, cols, -1.0, 1.0);
+        }
+        RSP_HIP(hipGetLastError());
+        F->guard.end(st);
+        return (int)RSP_OK;
+    });
+}
+
 void rsp_mat_free(rsp_mat *M) { delete M; }
 
 int rsp_gaxpy_f64(const rsp_csc_f64 *A, const double *x, const double *y, double *r)
@@ -544,6 +580,18 @@ int rsp_sqr_lu(const rsp_csc_f64 *A, int8_t order, rsp_symb **S)
     return guarded([&] {
         std::unique_ptr<rsp_symb> h(new rsp_symb);
         h->s = symbolic_lu(view_of(A), order);
+        *S = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_sqr_qr(const rsp_csc_f64 *A, int8_t order, rsp_symb **S)
+{
+    if (!sane_indices(A) || !S) return RSP_BAD_INPUT;
+    *S = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_symb> h(new rsp_symb);
+        h->s = symbolic_qr(view_of(A), order);
         *S = h.release();
         return (int)RSP_OK;
     });
@@ -592,6 +640,9 @@ const int64_t *rsp_symb_q(const rsp_symb *S) { return (S && S->s.has_q) ? S->s.q
 const int64_t *rsp_symb_parent(const rsp_symb *S) { return (S && !S->s.parent.empty()) ? S->s.parent.data() : nullptr; }
 const int64_t *rsp_symb_cp(const rsp_symb *S) { return (S && !S->s.cp.empty()) ? S->s.cp.data() : nullptr; }
 int64_t rsp_symb_lnz(const rsp_symb *S) { return S ? S->s.lnz : 0; }
+int64_t rsp_symb_m2(const rsp_symb *S) { return S ? S->s.m2 : 0; }
+int64_t rsp_symb_pinv_len(const rsp_symb *S) { return (S && S->s.has_pinv) ? (int64_t)S->s.pinv.size() : 0; }
+int64_t rsp_symb_cp_len(const rsp_symb *S) { return S ? (int64_t)S->s.cp.size() : 0; }
 int64_t rsp_symb_unz(const rsp_symb *S) { return S ? S->s.unz : 0; }
 void rsp_symb_free(rsp_symb *S) { delete S; }
 
@@ -936,6 +987,104 @@ int rsp_lu_solve_dev_f64(rsp_lu *N, const rsp_symb *S, double *dB, int layout, i
 }
 
 void rsp_lu_free(rsp_lu *N) { delete N; }
+
+// ---- QR: the consumer of usolve / utsolve (qrsol, lib.rs:927-956) ------------------------------------------------
+int rsp_qr_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_qr **N)
+{
+    if (!sane_indices(A) || !S || !N || S->s.n != A->n) return RSP_BAD_INPUT;
+    *N = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_qr> h(new rsp_qr);
+        h->m = A->m;
+        h->n = A->n;
+        if (int st = sparse_qr(view_of(A), S->s, h->f)) return st;
+        *N = h.release();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_qr_V(const rsp_qr *N, rsp_csc_f64 *V)
+{
+    if (!N || !V) return RSP_BAD_INPUT;
+    fill_view(N->f.V, V);
+    return RSP_OK;
+}
+int rsp_qr_R(const rsp_qr *N, rsp_csc_f64 *R)
+{
+    if (!N || !R) return RSP_BAD_INPUT;
+    fill_view(N->f.R, R);
+    return RSP_OK;
+}
+const double *rsp_qr_beta(const rsp_qr *N) { return N ? N->f.beta.data() : nullptr; }
+
+// x <- R^-1 x (kind 2, usolve) or R^-T x (kind 3, utsolve) on the GPU; R is m2 x n with every row index below n, so the
+// n x n view is the triangular matrix the solve needs (usolve only touches x[0, n), lib.rs:1230-1237)
+static int qr_triangular(rsp_qr *N, int kind, double *x, bool single_use)
+{
+    std::unique_ptr<TriSolver> &T = N->upper[kind - RSP_USOLVE];
+    if (!T) {
+        const Csc &R = N->f.R;
+        std::unique_ptr<TriSolver> t(new TriSolver);
+        if (int st = t->analyze(CscView{R.n, R.n, R.p.data(), R.i.data(), R.x.data()}, kind)) return st;
+        if (single_use) t->set_single_use();
+        T = std::move(t);
+    }
+    T->solve_host(x, N->n, 1);
+    return RSP_OK;
+}
+
+int rsp_qr_solve_f64(rsp_qr *N, const rsp_symb *S, double *b, int transposed)
+{
+    if (!N || !S || !b || S->s.n != N->n || S->s.m2 != N->f.V.m || (int64_t)S->s.pinv.size() != 2 * N->m + N->n) return RSP_BAD_INPUT;
+    if (N->m < N->n) return RSP_BAD_INPUT;  // the factored matrix must have at least as many rows as columns (qrsol factors A' otherwise)
+    return guarded([&] {
+        if (int st = require_device()) return st;
+        std::lock_guard<std::mutex> lock(N->guard.m);
+        const int64_t m = N->m, n = N->n;
+        const int64_t *rowperm = S->s.pinv.data(), *q = S->s.has_q ? S->s.q.data() : nullptr;
+        std::vector<double> x((size_t)S->s.m2, 0.0);
+        if (!transposed) {  // least squares with the factored matrix itself, lib.rs:931-942
+            for (int64_t i = 0; i < m; ++i) x[rowperm[i]] = b[i];          // ipvec(m, pinv, b, x)
+            qr_apply_reflections(N->f, false, x.data());                    // happly, k ascending
+            if (int st = qr_triangular(N, RSP_USOLVE, x.data(), false)) return st;  // x = R \ x
+            for (int64_t k = 0; k < n; ++k) b[q ? q[k] : k] = x[k];         // ipvec(n, q, x, b)
+        } else {  // the handle factors A' (m x n here = n_A x m_A): minimum-norm solution of A y = b, lib.rs:943-955
+            for (int64_t k = 0; k < n; ++k) x[k] = b[q ? q[k] : k];         // pvec(m_A, q, b, x)
+            if (int st = qr_triangular(N, RSP_UTSOLVE, x.data(), false)) return st;  // x = R' \ x
+            qr_apply_reflections(N->f, true, x.data());                     // happly, k descending
+            for (int64_t i = 0; i < m; ++i) b[i] = x[rowperm[i]];           // pvec(n_A, pinv, x, b)
+        }
+        return (int)RSP_OK;
+    });
+}
+
+void rsp_qr_free(rsp_qr *N) { delete N; }
+
+int rsp_qrsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
+{
+    if (!sane_indices(A) || !b) return RSP_BAD_INPUT;
+    rsp_symb *S = nullptr;
+    rsp_qr *N = nullptr;
+    int st;
+    if (A->m >= A->n) {
+        st = rsp_sqr_qr(A, order, &S);
+        if (st == RSP_OK) st = rsp_qr_f64(A, S, &N);
+        if (st == RSP_OK) st = rsp_qr_solve_f64(N, S, b, 0);
+    } else {
+        Csc At;
+        st = guarded([&] {
+            At = transpose_csc(view_of(A));
+            return (int)RSP_OK;
+        });
+        rsp_csc_f64 at{(int64_t)At.x.size(), At.m, At.n, At.p.data(), reinterpret_cast<const uint64_t *>(At.i.data()), At.x.data()};
+        if (st == RSP_OK) st = rsp_sqr_qr(&at, order, &S);
+        if (st == RSP_OK) st = rsp_qr_f64(&at, S, &N);
+        if (st == RSP_OK) st = rsp_qr_solve_f64(N, S, b, 1);
+    }
+    rsp_qr_free(N);
+    rsp_symb_free(S);
+    return st;
+}
 
 int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol)
 {

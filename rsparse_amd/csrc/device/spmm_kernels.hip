@@ -47,5 +47,19 @@ __global__ __launch_bounds__(256) void gaxpy_colmajor(CsrArrays A, int64_t rows,
     Y[r + c * ldy] = acc;
 }
 
+// dst = a * src + b * dst on a rows x cols block whose contiguous dimension is cols (b == 0: dst is only written).  The
+// glue of iterative refinement: W = B before the residual, X = X - W after the correction solve.
+__global__ __launch_bounds__(256) void block_axpby(double *__restrict__ dst, int64_t ld_dst, const double *__restrict__ src, int64_t ld_src,
+                                                   int64_t rows, int64_t cols, double a, double b)
+{
+#pragma clang fp contract(off)
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const double v = a * src[r * ld_src + c];
+        dst[r * ld_dst + c] = b == 0.0 ? v : v + b * dst[r * ld_dst + c];
+    }
+}
+
 }  // namespace dev
 }  // namespace rsp

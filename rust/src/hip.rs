@@ -17,6 +17,7 @@ extern "C" {
     fn rsp_utsolve_f64(u: *const Csc, x: *mut f64) -> i32;     // replaces utsolve  src/lib.rs:1271
     fn rsp_cholsol_f64(a: *const Csc, b: *mut f64, order: i8) -> i32;            // cholsol src/lib.rs:377
     fn rsp_lusol_f64  (a: *const Csc, b: *mut f64, order: i8, tol: f64) -> i32;  // lusol   src/lib.rs:672
+    fn rsp_qrsol_f64  (a: *const Csc, b: *mut f64, order: i8) -> i32;            // qrsol   src/lib.rs:927 (b: max(m, n) entries)
     // a loop of cholsol calls (src/lib.rs:377) over systems with ONE pattern: one analysis, one launch sequence
     fn rsp_cholsol_batch_f64(a: *const Csc, ax_all: *const f64, b: *mut f64, nsys: i64, order: i8, status: *mut i32) -> i32;
     fn rsp_symb_from_parts(n: i64, pinv: *const isize, q: *const isize, parent: *const isize, cp: *const isize,
@@ -38,6 +39,10 @@ fn status(code: i32) -> Option<Result<(), Error>> {
 pub(crate) fn lsolve_f64(l: &Sprs<f64>, x: &mut [f64]) -> bool { unsafe { rsp_lsolve_f64(&view(l), x.as_mut_ptr()) == 0 } }
 pub(crate) fn cholsol_f64(a: &Sprs<f64>, b: &mut [f64], order: i8) -> Option<Result<(), Error>> {
     status(unsafe { rsp_cholsol_f64(&view(a), b.as_mut_ptr(), order) })
+}
+/// true when the library solved the system; false (negative code): the caller runs the generic qrsol body.
+pub(crate) fn qrsol_f64(a: &Sprs<f64>, b: &mut [f64], order: i8) -> bool {
+    b.len() >= a.m.max(a.n) && unsafe { rsp_qrsol_f64(&view(a), b.as_mut_ptr(), order) } == 0
 }
 /// New public helper a maintainer may expose next to `cholsol`: `systems` share `pattern`'s p/i, `values[s]` are the
 /// entries of system s, `b[s]` its right-hand side.  Per-system result as `cholsol` would have returned it.

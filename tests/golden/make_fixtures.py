@@ -61,6 +61,21 @@ PLAN = {
     "allsol_1": dict(call="cholsol+lusol", order_chol=0, order_lu=1, lutol=1e-12, check="agree", tol=1e-12,
                      ref="tests/solver_tests.rs:928-946"),
     "allsol_2": dict(call="lusol", order=1, lutol=1e-12, check="residual", tol=1e-12, ref="tests/solver_tests.rs:949-968"),
+    # qrsol: the consumer of usolve / utsolve.  check "x": golden x; "residual": |A x - b| <= res_tol
+    # elementwise over the rows of A; "x+residual": both; transpose: the test transposes the loaded matrix first
+    "qrsol_1": dict(call="qrsol", order=2, check="x", tol=1e-1, ref="tests/solver_tests.rs:687-711"),
+    "qrsol_2": dict(call="qrsol", order=2, check="x", tol=1e-3, ref="tests/solver_tests.rs:714-753"),
+    "qrsol_3": dict(call="qrsol", order=2, check="x", tol=1e-3, ref="tests/solver_tests.rs:756-771"),
+    "qrsol_4": dict(call="qrsol", order=2, check="x", tol=1e-3, ref="tests/solver_tests.rs:774-789"),
+    "qrsol_5": dict(call="qrsol", order=2, check="x", tol=1e-3, ref="tests/solver_tests.rs:792-807"),
+    "qrsol_6": dict(call="qrsol", order=2, check="x", tol=1e-3, ref="tests/solver_tests.rs:810-846"),
+    "qrsol_7": dict(call="qrsol", order=2, check="x+residual", tol=1e-3, res_tol=1e-6, ref="tests/solver_tests.rs:849-890"),
+    "qrsol_8": dict(call="qrsol", order=2, check="residual", res_tol=1e-6, ref="tests/solver_tests.rs:893-906"),
+    "qrsol_9": dict(call="qrsol", order=2, check="residual", res_tol=1e-1, transpose=True, ref="tests/solver_tests.rs:909-925"),
+    "allsol_1_qr": dict(test="allsol_1", call="qrsol+cholsol", order=2, order_chol=0, check="agree", tol=1e-12,
+                        ref="tests/solver_tests.rs:928-946"),
+    "allsol_2_qr": dict(test="allsol_2", call="qrsol+lusol", order=2, order_lu=1, lutol=1e-12, check="agree+residual", tol=1e-1,
+                        res_tol=1e-12, ref="tests/solver_tests.rs:949-968"),
 }
 
 
@@ -112,9 +127,9 @@ def main():
     cases = {}
     tests = split_tests(open(os.path.join(REF, "tests/solver_tests.rs")).read())
     for name, plan in PLAN.items():
-        chunk = tests[name]
+        chunk = tests[plan.get("test", name)]
         vals = let_vectors(chunk)
-        case = dict(plan)
+        case = {k: v for k, v in plan.items() if k != "test"}
         m = re.search(r'load\("\.?/?tests/assets/(\w+\.sprs)"\)', chunk)
         if m:
             a = m.group(1)
@@ -128,7 +143,7 @@ def main():
             if key in flat:
                 case["b"] = flat[key]
                 break
-        if plan["check"] == "x":
+        if plan["check"] in ("x", "x+residual"):
             case["x"] = flat["x"]
         cases[name] = case
 

@@ -49,3 +49,27 @@ def to_scipy(A):
     import scipy.sparse as sp
     m, n, p, i, x = A
     return sp.csc_matrix((x, i, p), shape=(m, n))
+
+
+def to_dense(A):
+    m, n, p, i, x = A
+    out = np.zeros((m, n))
+    for j in range(n):
+        out[np.asarray(i[p[j]:p[j + 1]], np.int64), j] = x[p[j]:p[j + 1]]
+    return out
+
+
+def transpose_csc(A):
+    """Data helper for the one reference test that transposes its asset first (solver_tests.rs:921)."""
+    m, n, p, i, x = A
+    nz = int(p[n])
+    cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(p))
+    order = np.argsort(np.asarray(i[:nz], np.int64), kind="stable")
+    tp = np.zeros(m + 1, np.int64)
+    np.add.at(tp, np.asarray(i[:nz], np.int64) + 1, 1)
+    return (n, m, np.cumsum(tp), cols[order], np.asarray(x[:nz])[order])
+
+
+def qr_case(case):
+    A = case_matrix(case)
+    return transpose_csc(A) if case.get("transpose") else A

@@ -297,6 +297,57 @@ def test_host_blocks_with_a_leading_dimension_vs_oracle():
         assert rel_inf(big[:n, j], orc.trisolve("lsolve", L.as_tuple(), cols[j])) <= REL_X
 
 
+@pytest.mark.parametrize("layout", ["row", "col"])
+def test_refine_dev_vs_oracle(layout):
+    """rsp_chol_refine_dev_f64: from X = 0 one step IS the solve (against the oracle's cholsol); from a perturbed solution
+    one step comes back to it; a second step leaves the residual where it is; padding of the blocks is not touched."""
+    import torch
+    n, k = 1300, 5
+    A = synth.circuit_spd(n, 6, 61)
+    F = rs.CholHandle(A, rs.schol(A, 0))
+    M = rs.MatHandle(A)
+    Bh = 2.0 * synth.splitmix64(62, n * k).reshape(n, k) - 1.0
+    want = np.stack([orc.cholsol(A, Bh[:, j].copy(), 0)[1] for j in range(k)], axis=1)
+    row = layout == "row"
+    lay, ld, shape = (rs.api.ROW_MAJOR, k + 3, (n, k + 3)) if row else (rs.api.COL_MAJOR, n + 3, (k, n + 3))
+    def block(vals):
+        t = torch.full(shape, 77.0, dtype=torch.float64, device="cuda")
+        if row:
+            t[:, :k] = torch.tensor(vals, device="cuda")
+        else:
+            t[:, :n] = torch.tensor(vals.T.copy(), device="cuda")
+        return t
+    def values(t):
+        return t[:, :k].cpu().numpy() if row else t[:, :n].cpu().numpy().T
+    def padding(t):
+        return t[:, k:] if row else t[:, n:]
+    st = torch.cuda.current_stream().cuda_stream
+    B, W = block(Bh), block(np.zeros((n, k)))
+    X = block(np.zeros((n, k)))
+    F.refine_dev(M, B.data_ptr(), X.data_ptr(), W.data_ptr(), lay, ld, k, 1, st)
+    torch.cuda.synchronize()
+    assert rel_inf(values(X), want) <= REL_X and bool((padding(X) == 77.0).all()) and bool((padding(B) == 77.0).all())
+    noise = 1e-5 * (2.0 * synth.splitmix64(63, n * k).reshape(n, k) - 1.0)
+    X = block(want + noise)
+    F.refine_dev(M, B.data_ptr(), X.data_ptr(), W.data_ptr(), lay, ld, k, 1, st)
+    torch.cuda.synchronize()
+    once = values(X).copy()
+    assert rel_inf(once, want) <= REL_X
+    F.refine_dev(M, B.data_ptr(), X.data_ptr(), W.data_ptr(), lay, ld, k, 2, st)
+    torch.cuda.synchronize()
+    Ad = np.zeros((n, n))
+    m_, n_, p, i, x = A
+    for j in range(n):
+        Ad[i[p[j]:p[j + 1]].astype(np.int64), j] = x[p[j]:p[j + 1]]
+    res = lambda Xv: np.abs(Ad @ Xv - Bh).max() / np.abs(Bh).max()
+    assert res(values(X)) <= max(2.0 * res(once), 1e-14) and rel_inf(values(X), want) <= REL_X
+    # bad arguments: aliased blocks, a matrix of another size
+    with pytest.raises(rs.DeviceError):
+        F.refine_dev(M, B.data_ptr(), X.data_ptr(), X.data_ptr(), lay, ld, k, 1, st)
+    with pytest.raises(rs.DeviceError):
+        F.refine_dev(rs.MatHandle(synth.circuit_spd(n + 1, 6, 61)), B.data_ptr(), X.data_ptr(), W.data_ptr(), lay, ld, k, 1, st)
+
+
 # ---- device-resident lusol solve -------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("order", [1, -1])
@@ -474,3 +525,61 @@ def test_batch_sharded_over_devices():
             rs.set_devices([0, 99])
     finally:
         rs.set_devices([])
+
+
+# ---- qrsol: the consumer of usolve / utsolve (lib.rs:927-956) -------------------------------------------
+from helpers import qr_case, reference_cases, to_dense  # noqa: E402
+
+QR_SOLVER = reference_cases()["solver"]
+QR_CASES = [k for k, v in QR_SOLVER.items() if v["call"].startswith("qrsol")]
+
+
+@pytest.mark.parametrize("name", QR_CASES)
+def test_qrsol_reference_cases(name):
+    """Every qrsol test of the reference (tests/solver_tests.rs:687-968): its own assertions on the vector left in b,
+    and the same vector from the oracle's qrsol to REL_X (both branches: m >= n through usolve, m < n through utsolve)."""
+    c = QR_SOLVER[name]
+    A = qr_case(c)
+    m, n = A[0], A[1]
+    b0 = np.asarray(c["b"], np.float64)
+    got = b0.copy()
+    rs.qrsol(A, got, c["order"])
+    if "x" in c:
+        assert np.abs(got[:len(c["x"])] - np.asarray(c["x"])).max() <= c["tol"]
+    if "residual" in c["check"]:
+        assert np.abs(to_dense(A) @ got[:n] - b0[:m]).max() <= c["res_tol"]
+    if "agree" in c["check"]:
+        other = b0.copy()
+        if "cholsol" in c["call"]:
+            rs.cholsol(A, other, c["order_chol"])
+        else:
+            rs.lusol(A, other, c["order_lu"], c["lutol"])
+        assert np.abs(got - other).max() <= c["tol"]
+    want = orc.qrsol(A, b0, c["order"])
+    assert rel_inf(got[:n], want[:n]) <= REL_X
+
+
+def test_qr_handle_solves_many():
+    """rsp_qr_f64 once, rsp_qr_solve_f64 for several right-hand sides, least squares (tall matrix) and minimum norm
+    (its transpose factored, transposed = 1), against the oracle's qrsol and numpy's lstsq."""
+    tall = qr_case(dict(QR_SOLVER["qrsol_9"]))          # 201 x 200
+    wide = qr_case(dict(QR_SOLVER["qrsol_8"]))          # 200 x 201
+    S = rs.sqr(tall, 2, True)
+    N = rs.qr(tall, S)
+    D = to_dense(tall)
+    for seed in (1, 2, 3):
+        b = 2.0 * synth.splitmix64(seed, 201) - 1.0
+        got = b.copy()
+        N.solve(got)
+        want = orc.qrsol(tall, b, 2)
+        assert rel_inf(got[:200], want[:200]) <= REL_X
+        ls = np.linalg.lstsq(D, b, rcond=None)[0]
+        assert rel_inf(got[:200], ls) <= 1e-6
+        # the same handle factors wide' = tall: minimum-norm solution of wide y = c
+        c = np.zeros(201)
+        c[:200] = 2.0 * synth.splitmix64(10 + seed, 200) - 1.0
+        y = c.copy()
+        N.solve(y, transposed=True)
+        want = orc.qrsol(wide, c, 2)
+        assert rel_inf(y, want) <= REL_X
+        assert np.abs(to_dense(wide) @ y - c[:200]).max() <= 1e-9

@@ -363,3 +363,57 @@ def test_sprs_binary_format(tmp_path):
     open(tmp_path / "r.bin", "wb").write(bytes(bad))
     with pytest.raises(ValueError):
         ra.Sprs.load_bin(tmp_path / "r.bin")
+
+
+# ---- host QR (sqr(qr=true), qr): integers against the reference's pins and the oracle, values against the oracle ----
+def test_qr_symbolic_and_numeric_match_reference_pins():
+    import rsparse_amd as ra
+    pins = reference_cases()["structure"]
+    pin = pins["qr_1"]
+    A = load_sprs(pin["asset"])
+    S = ra.sqr(A, pin["order"], True)
+    assert S.q.tolist() == pin["sym.q"] and S.parent.tolist() == pin["sym.parent"] and S.cp.tolist() == pin["sym.cp"]
+    assert S.pinv.tolist() == pin["sym.pinv"] and (S.m2, S.lnz, S.unz) == (pin["sym.m2"], pin["sym.lnz"], pin["sym.unz"])
+    for name, nb in (("qr_1", 50), ("qr_2", 10)):
+        pin = pins[name]
+        A = load_sprs(pin["asset"])
+        N = ra.qr(A, ra.sqr(A, pin["order"], True))
+        V, R = N.l, N.u
+        assert V.i.tolist() == pin["qr.l.i"] and V.p.tolist() == pin["qr.l.p"] and R.i.tolist() == pin["qr.u.i"] and R.p.tolist() == pin["qr.u.p"]
+        assert (V.m, V.n, R.m, R.n) == (pin["qr.l.m"], pin["qr.l.n"], pin["qr.u.m"], pin["qr.u.n"])
+        nv = len(V.x)
+        assert np.abs(V.x - np.array(pin["qr.l.x~1e-6"][:nv])).max() <= 1e-6 and np.abs(R.x - np.array(pin["qr.u.x~1e-6"])).max() <= 1e-6
+        assert np.abs(N.b - np.array(pin["qr.b~1e-6"][:nb])).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name,order", [("cholsol_5.sprs", 2), ("lusol_4.sprs", 2), ("qrsol_8.sprs", 2), ("cholsol_2.sprs", 0), ("lusol_3.sprs", -1)])
+def test_qr_bitwise_vs_oracle(name, order):
+    """Same integers AND the same values bit for bit as the oracle's restatement of sqr + qr (lib.rs:788-877, 1114-1133):
+    one order of operations, no contraction on either side.  qrsol_8 is 200 x 201: factored as its transpose."""
+    import rsparse_amd as ra
+    from oracle import pyoracle as orc
+    from helpers import transpose_csc
+    A = load_sprs(name)
+    if A[0] < A[1]:
+        A = transpose_csc(A)
+    S = ra.sqr(A, order, True)
+    N = ra.qr(A, S)
+    o = orc.sqr_qr(A, order, numeric=True)
+    assert (S.q is None) == (o["q"] is None) and (S.q is None or np.array_equal(S.q, o["q"]))
+    assert np.array_equal(S.parent, o["parent"]) and np.array_equal(S.cp, o["cp"]) and np.array_equal(S.pinv, o["pinv"])
+    assert (S.m2, S.lnz, S.unz) == (o["m2"], o["lnz"], o["unz"])
+    V, R = N.l, N.u
+    nv, nr = int(o["Vp"][-1]), int(o["Rp"][-1])
+    assert np.array_equal(V.p, o["Vp"]) and np.array_equal(V.i.astype(np.int64), o["Vi"][:nv]) and np.array_equal(R.p, o["Rp"])
+    assert np.array_equal(R.i.astype(np.int64), o["Ri"][:nr])
+    assert np.array_equal(V.x.view(np.uint64), o["Vx"][:nv].view(np.uint64)) and np.array_equal(R.x.view(np.uint64), o["Rx"][:nr].view(np.uint64))
+    assert np.array_equal(N.b.view(np.uint64), o["beta"].view(np.uint64))
+
+
+def test_qr_rejects_foreign_symbolic():
+    import rsparse_amd as ra
+    A = load_sprs("cholsol_5.sprs")
+    with pytest.raises(ra.DeviceError):
+        ra.qr(A, ra.schol(A, 0))            # a Cholesky analysis: no QR row permutation
+    with pytest.raises(ra.DeviceError):
+        ra.qr(A, ra.sqr(load_sprs("cholsol_2.sprs"), 2, True))  # another matrix

@@ -79,3 +79,33 @@ def test_qr_2_integer_pins():
     _abs_close(out["Vx"], pin["qr.l.x~1e-6"][:23], 1e-6)
     _abs_close(out["Rx"], pin["qr.u.x~1e-6"], 1e-6)
     _abs_close(out["beta"], pin["qr.b~1e-6"][:10], 1e-6)
+
+
+# ---- qrsol: the consumer of usolve / utsolve; tests/solver_tests.rs:687-968 ----
+from helpers import qr_case, to_dense  # noqa: E402
+
+QR_CASES = [k for k, v in SOLVER.items() if v["call"].startswith("qrsol")]
+
+
+def check_qrsol_case(c, A, got, solve_other):
+    """The reference test's own assertions on the vector qrsol left in b."""
+    m, n = A[0], A[1]
+    b = np.asarray(c["b"], np.float64)
+    if "x" in c:
+        _abs_close(got, c["x"], c["tol"])
+    if "residual" in c["check"]:
+        assert np.abs(to_dense(A) @ got[:n] - b[:m]).max() <= c["res_tol"]
+    if "agree" in c["check"]:
+        _abs_close(got, solve_other(), c["tol"])
+
+
+@pytest.mark.parametrize("name", QR_CASES)
+def test_qrsol_golden(name):
+    c = SOLVER[name]
+    A = qr_case(c)
+    got = orc.qrsol(A, c["b"], c["order"])
+    def other():
+        if "cholsol" in c["call"]:
+            return orc.cholsol(A, c["b"], c["order_chol"])[1]
+        return orc.lusol(A, c["b"], c["order_lu"], c["lutol"])[1]
+    check_qrsol_case(c, A, got, other)
