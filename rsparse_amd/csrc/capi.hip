@@ -18,6 +18,7 @@
 #include "device/chol_engine.hpp"
 #include "device/engine.hpp"
 #include "host/parallel.hpp"
+#include "host/qr.hpp"
 
 using namespace rsp;
 

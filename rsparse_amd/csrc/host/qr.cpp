@@ -6,7 +6,7 @@
 // solves with R run on the GPU (capi.hip); everything here is host work by design, like lu.
 #include <cmath>
 
-#include "sparse.hpp"
+#include "qr.hpp"
 
 namespace rsp {
 

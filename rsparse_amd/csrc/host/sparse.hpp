@@ -51,13 +51,6 @@ struct LuFactors {
     std::vector<i64> pinv;
 };
 
-// rsparse::data::Nmrc for QR (data.rs:1064-1074): l = V (Householder vectors, diagonal first in every column),
-// u = R (m2 x n, diagonal last in every column), b = beta
-struct QrFactors {
-    Csc V, R;
-    std::vector<double> beta;
-};
-
 enum : int { kOk = 0, kNotPositiveDefinite = 1, kNoPivot = 2, kBadInput = -1, kDeviceError = -2 };
 
 // ---- ordering.cpp -------------------------------------------------------------------------------
@@ -88,16 +81,6 @@ std::vector<i64> fundamental_supernodes(const std::vector<i64> &parent, const st
 // lu (lib.rs:519-622) with threshold partial pivoting; q may be null (natural). Bit-exact pivot sequence,
 // L/U storage order and values (compiled with -ffp-contract=off).
 int sparse_lu(const CscView &A, const i64 *q, double tol, LuFactors &out);
-
-// ---- qr.cpp -------------------------------------------------------------------------------------
-// sqr(a, order, qr = true), lib.rs:1114-1133: q, parent (column etree), cp (n ROW counts of R), pinv (2m + n entries:
-// row permutation, n zeros, leftmost), m2, lnz = nnz(V), unz = nnz(R)
-Symbolic symbolic_qr(const CscView &A, int order);
-// qr, lib.rs:788-877.  kBadInput when S does not belong to A.
-int sparse_qr(const CscView &A, const Symbolic &S, QrFactors &out);
-// x <- H(n-1) .. H(0) x (reverse == false: the order qrsol uses for m >= n, lib.rs:937-940) or H(0) .. H(n-1) x
-void qr_apply_reflections(const QrFactors &F, bool reverse, double *x);
-Csc transpose_csc(const CscView &A);  // transpose, lib.rs:1178-1200
 
 // ---- schedule.cpp -------------------------------------------------------------------------------
 // A triangular solve in "gather" form: unknown r is computed from earlier unknowns,
