@@ -940,6 +940,7 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
         N->lower->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
         N->upper->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
         RSP_HIP(hipDeviceSynchronize());
+        if (N->lower->merged_failed() || N->upper->merged_failed()) return (int)RSP_DEVICE_ERROR;
         d.download(x.data(), x.size());
         const int64_t *q = S->s.has_q ? S->s.q.data() : nullptr;
         for (int64_t r = 0; r < nrhs; ++r)

@@ -246,6 +246,24 @@ class TriSolver {
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
     i64 scratch_cols_ = 0;
+    // Narrow blocks (at most 16 columns): runs of consecutive levels whose only work is the block kernel go out as ONE
+    // launch each (solve_levels_merged).  Built on the first narrow solve; the level descriptors do not depend on the
+    // number of columns below 17.
+    struct MergedTables {
+        bool built = false;
+        i64 key = -1;                      // the launch thresholds the tables were built for
+        DeviceBuffer<char> levels;         // dev::LevelDesc of every level in a run, run after run
+        DeviceBuffer<int> wg_begin;        // per run: its levels' first workgroups, plus one
+        DeviceBuffer<unsigned> counters;   // one flag word per workgroup of every run, then one sticky failure word
+        unsigned epoch = 0;                // of the last merged launch
+        std::vector<int> run_at;           // per level of the programme: index of the run that STARTS there, else -1
+        struct Run { int first_level, nlevels, desc_off, wg_off, total_wgs, flag_off; };
+        std::vector<Run> runs;
+    } merged_;
+
+   public:
+    // true if a merged launch ever gave up waiting (sticky; the results of that solve are not valid).  Synchronises.
+    bool merged_failed();
 };
 
 // first.solve then second.solve on one row-major device block, column halves pipelined over two streams
@@ -257,6 +275,7 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X_rowmajor, 
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)
 constexpr i64 kTaskEntriesMulti = 2048;   // unblocked fallback programme
 constexpr i64 kTaskEntriesSingle = 512;
+constexpr i64 kMergedMinLevels = 2;  // shorter runs keep their plain launches
 constexpr i64 kLeanLaunchWorkgroups = 128;  // levels with at least this many 512-thread workgroups run the lean variant
 constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 right-hand sides: 3 parts are 2 % faster but re-read the
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)

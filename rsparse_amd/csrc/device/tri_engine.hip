@@ -470,11 +470,115 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
         for (const auto &lv : P.levels)
             total += (i64)lv.nclusters * nchunks + ((i64)(lv.ntasks[0] + lv.ntasks[1]) * nchunks + 7) / 8 + ((i64)lv.ntasks[2] * nchunks + 1) / 2 +
                      (i64)lv.ntasks[3] * nchunks;
+    // what the block kernel of one level runs, and with how many workgroups, for `chunks` column chunks per block
+    auto small_alone_of = [&](const BlockedProgram::Level &lv) { return lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves; };
+    auto describe = [&](const BlockedProgram::Level &lv, bool small_alone, int chunks, dev::LevelDesc &L) {
+        const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
+        L.task_begin = small_alone ? lv.task_begin[1] : lv.task_begin[0];
+        L.block_begin[0] = lv.block_begin[2];
+        L.block_begin[1] = lv.block_begin[3];
+        L.blk0 = small_alone ? lv.block_begin[1] : lv.block_begin[0];
+        L.rec0 = small_alone ? lv.rec_begin[1] : lv.rec_begin[0];
+        L.rec_begin[0] = lv.rec_begin[2];
+        L.rec_begin[1] = lv.rec_begin[3];
+        L.single = P.single_block_tasks ? 1 : 0;
+        L.ntasks = n01;
+        L.nblk[0] = lv.ntasks[2];
+        L.nblk[1] = lv.ntasks[3];
+        L.wg0 = (int)(((i64)n01 * chunks + 7) / 8);
+        L.wg1 = (int)(((i64)lv.ntasks[2] * chunks + 1) / 2);
+        L.wg2 = (int)((i64)lv.ntasks[3] * chunks);
+        return (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
+    };
+    const bool narrow_block = nrhs <= 16;
+    const i64 lean_threshold = nrhs == 1 ? lean_wgs_single : lean_wgs;
+
+    // ---- narrow blocks: runs of consecutive block-kernel-only levels as one launch each -------------------------------
+    // OFF by default: measured at C2 with one right-hand side, a level inside a merged launch costs ~13 us (agent-scope
+    // release + acquire, i.e. an L2 write-back and invalidate per workgroup, plus the flag's trip through memory) against
+    // ~9 us for a launch of its own: 2.87 ms per cholsol solve phase instead of 2.39.  RSP_MERGED=1 turns
+    // it on; the parity tests run both.
+    bool merged = narrow_block && env_or("RSP_MERGED", 0) != 0;
+    if (merged) {
+        const i64 key = lean_threshold * 1000003 + small_waves;
+        if (!(merged_.built && merged_.key == key)) {
+            if (scratch_override) {
+                merged = false;  // the allocation-free entry point builds nothing
+            } else {
+                MergedTables &T = merged_;
+                T.runs.clear();
+                T.run_at.assign(P.levels.size(), -1);
+                std::vector<dev::LevelDesc> descs, cur;
+                std::vector<int> wg_begin, cur_wgs;
+                int cur_first = 0, flag_words = 0;
+                auto flush = [&] {
+                    if ((i64)cur.size() >= kMergedMinLevels) {
+                        MergedTables::Run R{cur_first, (int)cur.size(), (int)descs.size(), (int)wg_begin.size(), 0, flag_words};
+                        wg_begin.push_back(0);
+                        for (size_t k = 0; k < cur.size(); ++k) {
+                            descs.push_back(cur[k]);
+                            R.total_wgs += cur_wgs[k];
+                            wg_begin.push_back(R.total_wgs);
+                        }
+                        flag_words += R.total_wgs;
+                        T.run_at[cur_first] = (int)T.runs.size();
+                        T.runs.push_back(R);
+                    }
+                    cur.clear();
+                    cur_wgs.clear();
+                };
+                for (size_t li = 0; li < P.levels.size(); ++li) {
+                    const auto &lv = P.levels[li];
+                    const bool small_alone = small_alone_of(lv);
+                    dev::LevelDesc L;
+                    const unsigned padded = describe(lv, small_alone, 1, L);
+                    const int wgs = L.wg0 + L.wg1 + L.wg2;  // merged launches do not pad levels to whole XCD rounds
+                    // levels of few workgroups only: the deep-ring variant, and a wait that one wavefront can poll
+                    const bool joins = !lv.nclusters && !small_alone && wgs > 0 && padded < (unsigned)lean_threshold &&
+                                       wgs <= dev::kMergedMaxLevelWorkgroups;
+                    if (!joins) {
+                        flush();
+                        continue;
+                    }
+                    if (cur.empty()) cur_first = (int)li;
+                    cur.push_back(L);
+                    cur_wgs.push_back(wgs);
+                }
+                flush();
+                if (!descs.empty()) {
+                    T.levels.resize(descs.size() * sizeof(dev::LevelDesc));
+                    RSP_HIP(hipMemcpy(T.levels.get(), descs.data(), descs.size() * sizeof(dev::LevelDesc), hipMemcpyHostToDevice));
+                    T.wg_begin.upload(wg_begin.data(), wg_begin.size());
+                    T.counters.resize((size_t)flag_words + 1);
+                    RSP_HIP(hipMemset(T.counters.get(), 0, T.counters.size() * sizeof(unsigned)));
+                    T.epoch = 0;
+                }
+                T.key = key;
+                T.built = true;
+            }
+        }
+    }
+
     bool recorded = false;
-    for (const auto &lv : P.levels) {
+    for (size_t li = 0; li < P.levels.size(); ++li) {
+        const auto &lv = P.levels[li];
         if (after_heavy && !recorded && done * 10 >= total * 9) {
             RSP_HIP(hipEventRecord(after_heavy, stream));
             recorded = true;
+        }
+        if (merged && merged_.run_at[li] >= 0) {
+            const MergedTables::Run &R = merged_.runs[merged_.run_at[li]];
+            if (++merged_.epoch == 0) {  // wrapped after 2^32 launches: old flag words could match again, start over
+                RSP_HIP(hipMemsetAsync(merged_.counters.get(), 0, (merged_.counters.size() - 1) * sizeof(unsigned), stream));
+                merged_.epoch = 1;
+            }
+            const dev::MergedRun M{reinterpret_cast<const dev::LevelDesc *>(merged_.levels.get()) + R.desc_off, merged_.wg_begin.get() + R.wg_off,
+                                   merged_.counters.get() + R.flag_off, merged_.counters.get() + merged_.counters.size() - 1, R.nlevels, merged_.epoch};
+            auto kernel = fast ? dev::solve_levels_merged<true, true, 1> : dev::solve_levels_merged<false, true, 1>;
+            hipLaunchKernelGGL(kernel, dim3((unsigned)R.total_wgs), dim3(512), 7 * 8192, stream, A, M, X, ld, Sw, lds, (int)nrhs, 1);
+            done += R.total_wgs;
+            li += (size_t)R.nlevels - 1;
+            continue;
         }
         done += (i64)lv.nclusters * nchunks + ((i64)lv.ntasks[0] * nchunks + 7) / 8;
         if (lv.nclusters && P.dense) {  // dense tasks: one single-wavefront workgroup per (task, 16 * NT columns)
@@ -499,54 +603,35 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
                                lv.nclusters, nchunks, X, ld, (int)nrhs, P.cluster_slots, cpw);
         }
         // many small-block tasks: their own lean, high-occupancy launch; a few ride along with class 1
-        const bool small_alone = lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves;
+        const bool small_alone = small_alone_of(lv);
         if (small_alone)
             hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)((((i64)lv.ntasks[0] * nchunks + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
                                stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, Sw, lds, (int)nrhs, nchunks, lv.block_begin[0], lv.rec_begin[0],
                                P.single_block_tasks ? 1 : 0);
-        const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
-        if (n01 + lv.ntasks[2] + lv.ntasks[3]) {
-            dev::LevelDesc L;
-            L.task_begin = small_alone ? lv.task_begin[1] : lv.task_begin[0];
-            L.block_begin[0] = lv.block_begin[2];
-            L.block_begin[1] = lv.block_begin[3];
-            L.blk0 = small_alone ? lv.block_begin[1] : lv.block_begin[0];
-            L.rec0 = small_alone ? lv.rec_begin[1] : lv.rec_begin[0];
-            L.rec_begin[0] = lv.rec_begin[2];
-            L.rec_begin[1] = lv.rec_begin[3];
-            L.single = P.single_block_tasks ? 1 : 0;
-            L.ntasks = n01;
-            L.nblk[0] = lv.ntasks[2];
-            L.nblk[1] = lv.ntasks[3];
-            auto wgs_for = [&](int chunks) {
-                L.wg0 = (int)(((i64)n01 * chunks + 7) / 8);
-                L.wg1 = (int)(((i64)lv.ntasks[2] * chunks + 1) / 2);
-                L.wg2 = (int)((i64)lv.ntasks[3] * chunks);
-                return (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
-            };
-            unsigned wgs = wgs_for(nchunks);
+        dev::LevelDesc L;
+        unsigned wgs = describe(lv, small_alone, nchunks, L);
+        if (wgs) {
             // Few workgroups: a workgroup's own chain (round trips, then its matrix-core time) is the launch's duration --
             // the deep-ring variant, and 16 columns per wavefront instead of 64 so that four times as many compute units
             // share the work.  Many: the lean variant at twice the occupancy.
-            const bool pipe = wgs < (unsigned)(nrhs == 1 ? lean_wgs_single : lean_wgs);
+            const bool pipe = wgs < (unsigned)lean_threshold;
             const i64 narrow = env_or("RSP_LAT_NARROW", 1);
             int level_chunks = nchunks;
-            const bool nt1 = pipe && narrow && nrhs > 16;  // (blocks of at most 16 columns: see narrow_block below)
+            const bool nt1 = pipe && narrow && nrhs > 16;  // (blocks of at most 16 columns: see narrow_block)
             if (nt1) {
                 level_chunks = (int)((nrhs + 15) / 16);
-                wgs = wgs_for(level_chunks);
+                wgs = describe(lv, small_alone, level_chunks, L);
             }
             // Blocks of at most 16 columns (one right-hand side among them) always run 16-column wavefronts (one column
             // tile: a quarter of the registers), lean on heavy levels.  Wider UNALIGNED blocks (element-wise path) have no
             // lean variant: their selects need the registers of the deep-ring one.
-            const bool narrow_block = nrhs <= 16;
             auto kernel = narrow_block ? (fast ? (pipe ? dev::solve_level<true, true, 1> : dev::solve_level<true, false, 1>)
                                                : (pipe ? dev::solve_level<false, true, 1> : dev::solve_level<false, false, 1>))
                         : fast ? (nt1 ? dev::solve_level<true, true, 1> : pipe ? dev::solve_level<true, true, 4> : dev::solve_level<true, false, 4>)
                                        : (nt1 ? dev::solve_level<false, true, 1> : dev::solve_level<false, true, 4>);
             if (narrow_block && !nt1) {
                 level_chunks = 1;
-                wgs = wgs_for(level_chunks);
+                wgs = describe(lv, small_alone, level_chunks, L);
             }
             hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, level_chunks);
             done += wgs;
@@ -710,6 +795,14 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
     RSP_HIP(hipGetLastError());
 }
 
+bool TriSolver::merged_failed()
+{
+    if (!merged_.built || merged_.counters.size() == 0) return false;
+    unsigned flag = 0;
+    RSP_HIP(hipMemcpy(&flag, merged_.counters.get() + merged_.counters.size() - 1, sizeof(flag), hipMemcpyDeviceToHost));
+    return flag != 0;
+}
+
 void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
 {
     if (nrhs <= 0 || n_ == 0) return;
@@ -717,6 +810,7 @@ void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
     copy_block_to_device(d.get(), X, n_, ldx, nrhs);
     solve_device(d.get(), 0, n_, nrhs, nullptr);
     RSP_HIP(hipDeviceSynchronize());
+    if (merged_failed()) throw DeviceError("a merged-level launch gave up waiting for its previous level");
     copy_block_to_host(X, d.get(), n_, ldx, nrhs);
 }
 

@@ -455,6 +455,8 @@ VARIANTS = [
     {"RSP_TRI_SINGLE": "1"},                              # ... for one right-hand side
     {"RSP_SPLIT_SOURCES": "32", "RSP_SPLIT8_SOURCES": "64", "RSP_MAX_BLOCK_SOURCES": "128"},  # more split blocks, partial sums
     {"RSP_TASK_BLOCKS": "3"},                             # several dependent blocks per wavefront (long unsplit blocks)
+    {"RSP_MERGED": "1"},                                  # narrow blocks: runs of deep-ring levels as one launch each
+    {"RSP_MERGED": "1", "RSP_LEAN_WGS": "1000000"},       # ... every level deep-ring: the longest runs
 ]
 
 
@@ -490,6 +492,33 @@ def test_every_switch_variant_vs_oracle(env, monkeypatch):
     rs.solve_pair_dev(lo, up, X.data_ptr(), nrhs, nrhs, stream)
     torch.cuda.synchronize()
     assert rel_inf(X.cpu().numpy()[:, [0, 100, 191]], want) <= REL_X
+
+
+def test_merged_level_launches_repeat(monkeypatch):
+    """RSP_MERGED=1: several levels per launch, workgroups of a level waiting on the flags of the previous one.  A
+    deeper factor than the variant test's, many solves in a row on one handle (the epoch in the flag words advances with
+    every launch), 1 and 16 columns, against the oracle; the host entry point reports no abandoned wait."""
+    torch = _torch()
+    monkeypatch.setenv("RSP_MERGED", "1")
+    A = synth.laplacian_2d(160, 160)
+    n = A[0]
+    F = rs.CholHandle(A, rs.schol(A, 0))
+    stream = torch.cuda.current_stream().cuda_stream
+    b = 2.0 * synth.splitmix64(5, n) - 1.0
+    st, want = orc.cholsol(A, b.copy(), 0)
+    assert st == orc.OK
+    for rep in range(6):
+        x = torch.tensor(b, device="cuda:0")
+        F.solve_dev(x.data_ptr(), rs.api.COL_MAJOR, n, 1, True, stream)
+        torch.cuda.synchronize()
+        assert rel_inf(x.cpu().numpy(), want) <= REL_X, rep
+    X = torch.tensor(np.stack([b * (c + 1) for c in range(16)], axis=1).copy(), device="cuda:0")
+    F.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, 16, 16, True, stream)
+    torch.cuda.synchronize()
+    assert rel_inf(X.cpu().numpy()[:, 15], 16.0 * want) <= REL_X
+    h = b.copy()
+    F.solve(h)  # host entry point: checks the sticky failure word after its synchronisation
+    assert rel_inf(h, want) <= REL_X
 
 
 @pytest.mark.parametrize("env", [{"RSP_CHOL_GROUPED": "0"}, {"RSP_CHOL_TINY": "0"}, {"RSP_CHOL_FUSE_WAVES": "0"}, {"RSP_CHOL_FUSE_WAVES": "100000"},
