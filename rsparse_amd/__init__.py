@@ -1,8 +1,8 @@
 """rsparse_amd -- host-side mirror of rsparse's numeric solve path over librsparse_hip.so (MI355X / gfx950).
 
 Same function names, argument meaning and error behaviour as the reference's public API for this path
-(/root/reference/src/lib.rs): lsolve, ltsolve, usolve, utsolve, schol, chol, cholsol, sqr, lu, lusol on
-`Sprs` matrices.  Symbolic analysis runs on the host inside the library, numeric work on the GPU.
+(/root/reference/src/lib.rs): lsolve, ltsolve, usolve, utsolve, schol, chol, cholsol, sqr, lu, lusol, qr, qrsol,
+gaxpy on `Sprs` matrices (and `Sprs.save` / `Sprs.load`, src/data.rs:414-516).  Symbolic analysis runs on the host inside the library, numeric work on the GPU.
 There is no CPU fallback: importing fails loudly if the HIP library has not been built
 (`make -C rsparse_amd/csrc`, or `python -c "import __graft_entry__ as g; g.build()"`).
 """
