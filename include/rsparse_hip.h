@@ -112,6 +112,12 @@ void rsp_tri_free(rsp_tri *h);
  * that many LDS slots, cluster_slots < 0 dense matrix-core tasks of -cluster_slots slots (the bottom of the forest). */
 int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
                              double *max_rel_error);
+/* Host-only check of the REFILL of a programme (debug aid, no GPU): the programme of T is built, the values `new_values`
+ * (same pattern, nnz entries) are poured into it through its recipe, and the result is compared bit for bit with a
+ * programme emitted from scratch for the new values.  report[0] = 1 if the programme carries a recipe (0: duplicate
+ * entries or an oversized inverse pool -- such programmes are always emitted again), report[1] = coefficient entries that
+ * differ, report[2] = cluster records that differ, report[3] = coefficient entries. */
+int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int kind, int64_t task_blocks, int cluster_slots, int64_t *report);
 
 /* The same for the SUPERNODAL programme (dense LDS tasks at the bottom of the forest, supernode products above; debug aid,
  * host only, no reference counterpart).  options (may be NULL) = {task slots (< 0: no tasks), widest node with folded

@@ -19,6 +19,7 @@ from .api import (  # noqa: F401
     Symb,
     TriHandle,
     validate_program,
+    validate_refill,
     validate_supernodal,
     amd,
     chol,

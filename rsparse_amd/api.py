@@ -69,6 +69,7 @@ def lib():
             "rsp_tri_levels": (cint, [vp, vp]),
             "rsp_tri_free": (None, [vp]),
             "rsp_tri_validate_program": (cint, [csc, cint, i64, cint, vp, vp]),
+            "rsp_tri_validate_refill": (cint, [csc, vp, cint, i64, cint, vp]),
             "rsp_tri_validate_supernodal": (cint, [csc, cint, vp, vp, vp]),
             "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
@@ -534,6 +535,17 @@ def validate_program(t, kind, task_blocks=0, cluster_slots=0):
     d = dict(zip(keys, rep.tolist()))
     d["max_rel_error"] = err.value
     return d
+
+
+def validate_refill(t, new_values, kind, task_blocks=0, cluster_slots=0):
+    """Host-only check that new values poured into the programme of `t` through its recipe give, bit for bit, the programme
+    emitted from scratch for those values (rsp_tri_validate_refill); no GPU needed."""
+    t = _as_sprs(t)
+    v = np.ascontiguousarray(new_values, np.float64)
+    assert v.shape == (int(t.p[t.n]),)
+    rep = np.zeros(4, np.int64)
+    _check(lib().rsp_tri_validate_refill(C.byref(t._view()), v.ctypes.data, kind, task_blocks, cluster_slots, rep.ctypes.data))
+    return dict(zip(("has_recipe", "coef_mismatches", "group_mismatches", "coef_entries"), rep.tolist()))
 
 
 def validate_supernodal(t, kind, task_slots=0, small_node=0, max_node=0, max_item_k=0):

@@ -345,6 +345,39 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
     });
 }
 
+int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int kind, int64_t task_blocks, int cluster_slots, int64_t *report)
+{
+    if (!sane(T) || !new_values || !report) return RSP_BAD_INPUT;
+    return guarded([&] {
+        const int slots = cluster_slots > 0 ? cluster_slots : kClusterSlots;
+        const int64_t blocks = task_blocks > 0 ? task_blocks : kTaskBlocks;
+        GatherForm G;
+        G.keep_src = true;
+        if (int st = build_gather_form(view_of(T), kind, G)) return st;
+        BlockProgram P = build_block_program(G, blocks, slots, false);
+        CscView T2 = view_of(T);
+        T2.x = new_values;
+        report[0] = P.refill.valid ? 1 : 0;
+        report[1] = report[2] = 0;
+        report[3] = (int64_t)P.coef.size();
+        if (!P.refill.valid) return (int)RSP_OK;
+        fill_gather_values(T2, kind, G);
+        if (!refill_block_program(G, P)) return (int)RSP_INTERNAL_ERROR;
+        GatherForm G2;
+        if (int st = build_gather_form(T2, kind, G2)) return st;
+        const BlockProgram Q = build_block_program(G2, blocks, slots, false);
+        if (Q.coef.size() != P.coef.size() || Q.groups.size() != P.groups.size()) return (int)RSP_INTERNAL_ERROR;
+        auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; };
+        for (size_t e = 0; e < P.coef.size(); ++e) report[1] += !same(P.coef[e], Q.coef[e]);
+        for (size_t g = 0; g < P.groups.size(); ++g) {
+            bool ok = same(P.groups[g].rdiag, Q.groups[g].rdiag);
+            for (int e = 0; e < 4; ++e) ok = ok && same(P.groups[g].coef[e], Q.groups[g].coef[e]);
+            report[2] += !ok;
+        }
+        return (int)RSP_OK;
+    });
+}
+
 int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *options, int64_t *report, double *max_rel_error)
 {
     if (!sane(T) || kind < 0 || kind > 3 || !report || !max_rel_error) return RSP_BAD_INPUT;

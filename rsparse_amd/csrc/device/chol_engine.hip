@@ -488,8 +488,12 @@ int CholFactor::factorize(const CscView &A)
 // system s with a pivot <= 0, or INT_MAX.  All systems go through the same launches (grid.y = system).
 void CholFactor::factorize_values(const double *Ax_all, i64 nsys, int32_t *first_bad)
 {
-    lower_.reset();
-    upper_.reset();
+    if (nsys == 1 && lower_ && upper_) {
+        solvers_stale_ = true;  // same pattern: the resident solve programmes only need the new values (build_solvers)
+    } else {
+        lower_.reset();
+        upper_.reset();
+    }
     batch_ = nsys;
     hipStream_t stream = nullptr;
     hipEvent_t ev0, ev1;
@@ -618,11 +622,62 @@ void CholFactor::download(i64 *Lp, i64 *Li, double *Lx) const
 
 void CholFactor::build_solvers()
 {
-    if (lower_) return;
+    if (lower_ && !solvers_stale_) return;
     join_pattern_jobs();
+    const double t0 = now_s();
+    if (lower_ && upper_ && solvers_stale_) {
+        // refactorised: the resident programmes take the new values straight from d_Lx (kernels; nothing crosses PCIe).
+        // The debugging switches that run the plain level programmes need the values on the host: host path below.
+        const auto on = [](const char *name, char v) { return getenv(name) && getenv(name)[0] == v; };
+        const bool device_refill = !on("RSP_REFILL_DEVICE", '0') && !on("RSP_TRI_SINGLE", '1') && !on("RSP_TRI_BLOCKED", '0');
+        const CscView Lpat{n_, n_, Lp_.data(), Li_.data(), nullptr};
+        RSP_HIP(hipDeviceSynchronize());  // nothing may still be reading the coefficients that are about to change
+        if (device_refill && lower_->refresh_device(Lpat, d_Lx.get(), nullptr) && upper_->refresh_device(Lpat, d_Lx.get(), nullptr)) {
+            RSP_HIP(hipStreamSynchronize(nullptr));  // the solve that follows may run on any stream
+            solvers_stale_ = false;
+            if (getenv("RSP_TIMING")) fprintf(stderr, "chol solvers: new values into the resident programmes on the device %.4fs\n", now_s() - t0);
+            return;
+        }
+    }
     std::vector<double> Lx((size_t)lnz_);
     d_Lx.download(Lx.data(), Lx.size());
     const CscView L{n_, n_, Lp_.data(), Li_.data(), Lx.data()};
+    if (lower_ && upper_ && solvers_stale_) {
+        // refactorised: pour the new values into the resident programmes (both triangles side by side on the host), no
+        // analysis and no emission; anything the recipe does not cover falls through to the full analysis below
+        RSP_HIP(hipDeviceSynchronize());  // nothing may still be reading the coefficients that are about to change
+        bool ok_lower = false, ok_upper = false;
+        std::exception_ptr eb;
+        std::thread other([&] {
+            try {
+                ok_upper = upper_->refresh_host(L);
+            } catch (...) {
+                eb = std::current_exception();
+            }
+        });
+        try {
+            ok_lower = lower_->refresh_host(L);
+        } catch (...) {
+            other.join();
+            throw;
+        }
+        other.join();
+        if (eb) std::rethrow_exception(eb);
+        if (ok_lower && ok_upper) {
+            const double t1 = now_s();
+            lower_->refresh_upload();
+            upper_->refresh_upload();
+            solvers_stale_ = false;
+            if (getenv("RSP_TIMING"))
+                fprintf(stderr, "chol solvers: new values into the resident programmes %.3fs (download + host refill) + %.3fs (upload)\n", t1 - t0,
+                        now_s() - t1);
+            return;
+        }
+        lower_.reset();
+        upper_.reset();
+    }
+    solvers_stale_ = false;
+    const bool refill = !single_use_ && !(getenv("RSP_REFILL") && getenv("RSP_REFILL")[0] == '0');
     if (pat_lower_ && pat_upper_ && pat_status_[0] == kOk && pat_status_[1] == kOk) {
         // the patterns were analysed beside the factorisation: add the values, then stage what the solve will run
         std::unique_ptr<TriSolver> lo = std::move(pat_lower_), up = std::move(pat_upper_);
@@ -649,6 +704,10 @@ void CholFactor::build_solvers()
     pat_lower_.reset();
     pat_upper_.reset();
     std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
+    if (refill) {  // a handle that may be refactorised: keep what a refill of the programmes needs
+        lo->keep_for_refill();
+        up->keep_for_refill();
+    }
     if (analyze_pair(*lo, L, 0, *up, L, 1, single_use_) != kOk) throw DeviceError("factor is not a valid triangular matrix");
     lower_ = std::move(lo);
     upper_ = std::move(up);

@@ -211,6 +211,22 @@ class TriSolver {
     // blocked programme for a single use.  Handles that solve many times never call this.
     void set_single_use();
     bool single_use_levels() const { return single_use_levels_; }
+    // NEW VALUES ON THE ANALYSED PATTERN (a refactorisation).  keep_for_refill() before analyze(): the gather form keeps
+    // where each of its values comes from and the blocked programme keeps its recipe (BlockProgram::Refill) and a host
+    // copy of its coefficients.  refresh_host(T) then pours the values of T (same pattern) into that copy -- host work
+    // only, any thread -- and refresh_upload() sends coefficients and cluster records to the resident programme.
+    // refresh_host returns false when there is nothing to refresh in place (no resident blocked programme, no recipe):
+    // the caller analyses again.
+    void keep_for_refill() { G_.keep_src = true; }
+    bool refresh_host(const CscView &T);
+    void refresh_upload();
+    // The same on the device, from the factor's values where the factorisation left them (dTx; T gives the pattern
+    // only): gather kernels for coefficients and cluster records, the 16 x 16 triangles and the chain blocks inverted by
+    // kernels (refill_kernels.hip).  The recipe goes to the device at the first call.  Asynchronous on `stream`.  false:
+    // not available for this programme (no recipe, duplicate entries inside a chain) -- use refresh_host.  The host copy
+    // of the gather form keeps the OLD values afterwards: the plain level programmes cannot be built from it any more
+    // (DeviceError) until a refresh_host.
+    bool refresh_device(const CscView &T, const double *dTx, hipStream_t stream);
     void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
                     double *scratch_override = nullptr);
     // Row-major solve that allocates nothing: the blocked programme must already be resident (one earlier solve through
@@ -242,6 +258,19 @@ class TriSolver {
     bool sn_decided_ = false, use_sn_ = false, have_sn_ = false;
     std::unique_ptr<SnProgram> staged_sn_;
     std::unique_ptr<BlockProgram> staged_;
+    std::unique_ptr<BlockProgram> kept_;  // keep_for_refill(): coef, groups and the recipe of the resident programme
+    struct DeviceRecipe {
+        bool built = false, usable = false;
+        DeviceBuffer<int32_t> map, coef_src, grp_first, grp_row, chain_pos, chain_code;
+        DeviceBuffer<BlockProgram::Refill::Tri16> tri16;
+        DeviceBuffer<char> chains;  // dev::ChainDesc
+        DeviceBuffer<double> pool, mpool;
+        i64 ncoef = 0, ngroups = 0, ntri = 0, nchain_entries = 0, pool_size = 0;
+        int nchains = 0, ntiles = 0;
+        int32_t split = 0, nnz = 0;
+    } recipe_;
+    bool host_values_stale_ = false;  // refresh_device ran since the gather form last received values
+    void build_device_recipe(const CscView &T);
     std::unique_ptr<TriProgramHost> staged_single_;  // set_single_use(): the level programme, ready for upload
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers

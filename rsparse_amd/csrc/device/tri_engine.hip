@@ -15,6 +15,7 @@
 #include "dense_kernels.hip"
 #include "sn_kernels.hip"
 #include "task_kernels.hip"
+#include "refill_kernels.hip"
 
 namespace rsp {
 
@@ -42,6 +43,7 @@ int TriSolver::analyze(const CscView &T, int kind)
 
 TriProgramHost TriSolver::stage_program(i64 max_task_entries) const
 {
+    if (host_values_stale_) throw DeviceError("the level programme needs the factor's values on the host: refreshed on the device only");
     const Schedule S = build_schedule(G_, max_task_entries);
     TriProgramHost H;
     const i64 ntasks = (i64)S.task_first.size();
@@ -282,6 +284,7 @@ void TriSolver::run_window_supernodal(double *X, i64 ld, i64 nrhs, i64 col_off, 
 // host half of build_blocked(): no device call, so two solvers can be staged on two host threads
 void TriSolver::stage_blocked()
 {
+    if (host_values_stale_) throw DeviceError("the programme needs the factor's values on the host: refreshed on the device only");
     stage_supernodal();
     if (use_sn_) return;
     const bool dense = env_or("RSP_DENSE_TASKS", kDenseTasks) != 0;
@@ -409,6 +412,137 @@ void TriSolver::build_blocked()
     RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * (std::min(D.cluster_slots, 64) * 512 + 1024)));
     if (getenv("RSP_TIMING")) fprintf(stderr, "tri programme: build %.2fs, upload %.2fs\n", tb1 - tb0, now_s() - tb1);
+    kept_.reset();
+    if (G_.keep_src && P.refill.valid) {
+        kept_.reset(new BlockProgram);
+        kept_->coef = std::move(P.coef);
+        kept_->groups = std::move(P.groups);
+        kept_->refill = std::move(P.refill);
+    }
+}
+
+bool TriSolver::refresh_host(const CscView &T)
+{
+    if (!have_blocked_ || !kept_ || G_.src.empty() || T.n != n_ || T.nnz() + 0 != (i64)G_.src.size() + n_) return false;
+    fill_gather_values(T, kind_, G_);
+    host_values_stale_ = false;
+    return refill_block_program(G_, *kept_);
+}
+
+void TriSolver::build_device_recipe(const CscView &T)
+{
+    DeviceRecipe &D = recipe_;
+    D.built = true;
+    D.usable = false;
+    const BlockProgram::Refill &R = kept_->refill;
+    const i64 nnz = (i64)G_.src.size(), n = n_;
+    const bool lower_storage = kind_ == 0 || kind_ == 1;
+    // code -> entry of the factor: the gather form's sources, then the diagonals
+    std::vector<int32_t> map((size_t)(nnz + n));
+    std::copy(G_.src.begin(), G_.src.end(), map.begin());
+    for (i64 r = 0; r < n; ++r) map[(size_t)(nnz + r)] = (int32_t)(lower_storage ? T.p[r] : T.p[r + 1] - 1);
+    // group records: first entry of the gather form and row of each
+    const i64 ngroups = (i64)kept_->groups.size();
+    std::vector<int32_t> first((size_t)ngroups, -1), row((size_t)ngroups, 0);
+    for (const BlockProgram::Refill::Cluster &c : R.clusters) {
+        i64 g = c.grp_off;
+        for (i64 k = 0; k <= c.hi - c.lo; ++k) {
+            const i64 r = G_.descending ? c.hi - k : c.lo + k;
+            const i64 pb = G_.ptr[r], ng = std::max<i64>(1, (G_.ptr[r + 1] - pb + 3) / 4);
+            for (i64 gg = 0; gg < ng; ++gg, ++g) {
+                if (g >= ngroups) return;
+                first[g] = (int32_t)std::min<i64>(pb + 4 * gg, std::max<i64>(nnz - 1, 0));
+                row[g] = (int32_t)r;
+            }
+        }
+    }
+    for (int32_t f : first)
+        if (f < 0) return;  // a record no cluster owns: not a programme this recipe describes
+    // chains: descriptors, and the entries of the gather form that fall inside each diagonal block
+    std::vector<dev::ChainDesc> chains;
+    std::vector<int32_t> pos, code;
+    int tiles = 0;
+    std::vector<char> seen;
+    for (const BlockProgram::Refill::Chain &c : R.chains) {
+        const i64 w = c.t1 - c.t0;
+        chains.push_back(dev::ChainDesc{c.pool_off, (int32_t)w, tiles});
+        tiles += (int)((w + 63) / 64);
+        seen.assign((size_t)w, 0);
+        for (i64 t = c.t0; t < c.t1; ++t) {
+            const i64 r = G_.descending ? n - 1 - t : t;
+            std::fill(seen.begin(), seen.end(), 0);
+            pos.push_back((int32_t)(c.pool_off + (t - c.t0) * w + (t - c.t0)));
+            code.push_back((int32_t)(nnz + r));
+            seen[(size_t)(t - c.t0)] = 1;
+            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                const i64 ps = G_.descending ? n - 1 - G_.idx[p] : G_.idx[p];
+                if (ps < c.t0) continue;
+                if (seen[(size_t)(ps - c.t0)]) return;  // duplicate entries add up: the host refill handles those
+                seen[(size_t)(ps - c.t0)] = 1;
+                pos.push_back((int32_t)(c.pool_off + (t - c.t0) * w + (ps - c.t0)));
+                code.push_back((int32_t)p);
+            }
+        }
+    }
+    D.map.upload(map);
+    D.coef_src.upload(R.coef_src);
+    D.grp_first.upload(first);
+    D.grp_row.upload(row);
+    D.tri16.upload(R.tri16);
+    D.chain_pos.upload(pos);
+    D.chain_code.upload(code);
+    D.chains.resize(std::max<size_t>(1, chains.size() * sizeof(dev::ChainDesc)));
+    if (!chains.empty()) RSP_HIP(hipMemcpy(D.chains.get(), chains.data(), chains.size() * sizeof(dev::ChainDesc), hipMemcpyHostToDevice));
+    D.pool.resize((size_t)std::max<i64>(R.pool_size, 1));
+    D.mpool.resize((size_t)std::max<i64>(R.pool_size, 1));
+    D.ncoef = (i64)R.coef_src.size();
+    D.ngroups = ngroups;
+    D.ntri = (i64)R.tri16.size();
+    D.nchain_entries = (i64)pos.size();
+    D.pool_size = R.pool_size;
+    D.nchains = (int)chains.size();
+    D.ntiles = tiles;
+    D.split = (int32_t)(nnz + n);
+    D.nnz = (int32_t)nnz;
+    D.usable = true;
+}
+
+bool TriSolver::refresh_device(const CscView &T, const double *dTx, hipStream_t stream)
+{
+    if (!have_blocked_ || !kept_ || G_.src.empty() || T.n != n_ || T.nnz() != (i64)G_.src.size() + n_) return false;
+    if (!recipe_.built) build_device_recipe(T);
+    DeviceRecipe &D = recipe_;
+    if (!D.usable || D.ncoef != (i64)blocked_.coef.size() || D.ngroups > (i64)blocked_.groups.size()) return false;
+    const dev::RefillSource S{D.map.get(), dTx, D.pool.get(), D.split, D.nnz};
+    auto blocks = [](i64 count) { return dim3((unsigned)std::min<i64>((count + 255) / 256, 1 << 20)); };
+    if (D.pool_size) {
+        RSP_HIP(hipMemsetAsync(D.mpool.get(), 0, (size_t)D.pool_size * sizeof(double), stream));
+        RSP_HIP(hipMemsetAsync(D.pool.get(), 0, (size_t)D.pool_size * sizeof(double), stream));
+        hipLaunchKernelGGL(dev::chain_fill, blocks(D.nchain_entries), dim3(256), 0, stream, D.mpool.get(), D.chain_pos.get(), D.chain_code.get(),
+                           D.nchain_entries, S);
+        hipLaunchKernelGGL(dev::chain_invert, dim3((unsigned)D.ntiles), dim3(64), 0, stream, D.mpool.get(), D.pool.get(),
+                           reinterpret_cast<const dev::ChainDesc *>(D.chains.get()), D.nchains);
+    }
+    if (D.ntri)
+        hipLaunchKernelGGL(dev::refill_tri16, dim3((unsigned)((D.ntri + 15) / 16)), dim3(256), 0, stream, blocked_.coef.get(), D.tri16.get(), D.ntri, S);
+    if (D.ncoef) hipLaunchKernelGGL(dev::refill_coef, blocks(D.ncoef), dim3(256), 0, stream, blocked_.coef.get(), D.coef_src.get(), D.ncoef, S);
+    if (D.ngroups)
+        hipLaunchKernelGGL(dev::refill_groups, dim3((unsigned)((D.ngroups + 255) / 256)), dim3(256), 0, stream, blocked_.groups.get(), D.grp_first.get(),
+                           D.grp_row.get(), D.ngroups, S);
+    RSP_HIP(hipGetLastError());
+    host_values_stale_ = true;
+    have_single_ = have_multi_ = false;
+    staged_single_.reset();
+    return true;
+}
+
+void TriSolver::refresh_upload()
+{
+    blocked_.coef.upload(kept_->coef);
+    blocked_.groups.upload(kept_->groups);
+    // the plain level programmes carry values of their own: rebuilt from the gather form at their next use
+    have_single_ = have_multi_ = false;
+    staged_single_.reset();
 }
 
 void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)

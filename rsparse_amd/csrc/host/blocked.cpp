@@ -40,7 +40,83 @@ struct Triple {
     int32_t pos;   // processing position of the source (or scratch ordinal for phase-B blocks)
     int32_t slot;  // row slot inside the block
     double val;
+    int32_t code = -1;  // where val comes from (BlockProgram::Refill), -1: a constant
 };
+
+// ---- numeric pieces shared by the emitter and refill_block_program: one code, bit-identical results ----------------
+// Inverse of a chain's dense diagonal block.  Positions [t0, t1) of the processing order; M in position coordinates
+// (duplicate entries add up), then one forward substitution per column of the inverse.  Columns are dealt round-robin
+// to the host threads (column c costs (w - c)^2 / 2, so interleaving balances them); the result does not depend on
+// the number of threads.
+void chain_inverse(const GatherForm &G, i64 t0, i64 t1, std::vector<double> &Minv)
+{
+    const i64 n = G.n, w = t1 - t0;
+    auto row_at = [&](i64 t) { return G.descending ? n - 1 - t : t; };
+    auto pos_of = [&](i64 r) { return G.descending ? n - 1 - r : r; };
+    std::vector<double> M((size_t)w * w, 0.0);
+    for (i64 t = t0; t < t1; ++t) {
+        const i64 r = row_at(t);
+        M[(size_t)(t - t0) * w + (t - t0)] = G.diag[r];
+        for (i64 p = G.ptr[r]; p < G.ptr[r + 1]; ++p) {
+            const i64 ps = pos_of(G.idx[p]);
+            if (ps >= t0) M[(size_t)(t - t0) * w + (ps - t0)] += G.val[p];
+        }
+    }
+    Minv.assign((size_t)w * w, 0.0);
+    auto invert_columns = [&](i64 first, i64 stride) {
+        std::vector<double> z(w);
+        for (i64 c = first; c < w; c += stride) {
+            z[c] = 1.0 / M[(size_t)c * w + c];
+            for (i64 r = c + 1; r < w; ++r) {
+                const double *Mr = &M[(size_t)r * w];
+                double sum = 0.0;
+                for (i64 t = c; t < r; ++t) sum += Mr[t] * z[t];
+                z[r] = -sum / Mr[r];
+            }
+            for (i64 r = c; r < w; ++r) Minv[(size_t)r * w + c] = z[r];
+        }
+    };
+    // starting a thread costs tens of microseconds: only chains whose inverse takes milliseconds are shared out
+    const i64 nthreads = w >= 384 ? std::min<i64>(host_threads(), w / 64) : 1;
+    if (nthreads <= 1) {
+        invert_columns(0, 1);
+    } else {
+        std::vector<std::thread> pool;
+        for (i64 k = 0; k < nthreads; ++k) pool.emplace_back(invert_columns, k, nthreads);
+        for (std::thread &th : pool) th.join();
+    }
+}
+
+// inverse of a block's 16 x 16 lower triangle T (row-major, unit rows for padding), stored in the A-operand order of
+// v_mfma_f64_16x16x4_f64: K-step k, lane l holds Tinv[l & 15][4k + (l >> 4)]
+void store_tri16_inverse(const double (&T)[16][16], double *out)
+{
+    double Ti[16][16];
+    for (int r = 0; r < 16; ++r)
+        for (int t = 0; t < 16; ++t) Ti[r][t] = 0.0;
+    for (int c = 0; c < 16; ++c) {
+        Ti[c][c] = 1.0 / T[c][c];
+        for (int r = c + 1; r < 16; ++r) {
+            double sum = 0.0;
+            for (int t = c; t < r; ++t) sum += T[r][t] * Ti[t][c];
+            Ti[r][c] = -sum / T[r][r];
+        }
+    }
+    for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < 64; ++l) out[(size_t)k * 64 + l] = Ti[l & 15][4 * k + (l >> 4)];
+}
+
+// the group records of one cluster row: coefficients and reciprocal diagonal (the offsets are pattern)
+inline void fill_group_values(const GatherForm &G, i64 r, GroupRec *recs)
+{
+    const i64 pb = G.ptr[r], ne = G.ptr[r + 1] - pb;
+    const i64 ng = std::max<i64>(1, (ne + 3) / 4);
+    for (i64 g = 0; g < ng; ++g) {
+        const i64 cnt = std::max<i64>(0, std::min<i64>(4, ne - 4 * g));
+        for (i64 e = 0; e < 4; ++e) recs[g].coef[e] = e < cnt ? G.val[pb + 4 * g + e] : 0.0;
+        recs[g].rdiag = 1.0 / G.diag[r];
+    }
+}
 
 inline void sort_triples(std::vector<Triple> &src)  // by (pos, slot); most callers hand over sorted lists
 {
@@ -54,7 +130,7 @@ class Builder {
     Builder(const GatherForm &G, i64 max_blocks, int slots, bool dense)
         : G_(G), n_(G.n), max_blocks_(std::max<i64>(1, max_blocks)),
           slots_(dense ? std::min(slots, 4096) : std::min(slots, 64)),  // group-record clusters: one id per lane
-          dense_(dense)
+          dense_(dense), recipe_ok_(G.keep_src && !dense)
     {
         P_.dense = dense;
         avail_.assign(n_, 0);
@@ -96,6 +172,8 @@ class Builder {
         }
         clock_.lap(1);
         finish();
+        P_.refill.valid = recipe_ok_ && !dense_ && (i64)G_.idx.size() + n_ + P_.refill.pool_size < INT32_MAX;
+        if (!P_.refill.valid) P_.refill = BlockProgram::Refill();
         clock_.lap(2);
         if (std::getenv("RSP_TIMING"))
             std::fprintf(stderr, "programme build: clusters %.2fs, emission %.2fs (of which chains: matrix %.2fs, inverse %.2fs, blocks %.2fs + %.2fs), finish %.2fs\n",
@@ -358,6 +436,7 @@ class Builder {
             }
         }
         ClusterHeader h{(int32_t)ext.size(), (int32_t)n_own, 0, 0, (i64)P_.cluster_ids.size(), (i64)P_.groups.size()};
+        P_.refill.clusters.push_back(BlockProgram::Refill::Cluster{lo, hi, h.grp_off});
         P_.cluster_ids.insert(P_.cluster_ids.end(), ext.begin(), ext.end());
         for (i64 k = 0; k < n_own; ++k) {
             const i64 r = G_.descending ? hi - k : lo + k;
@@ -369,23 +448,16 @@ class Builder {
             const int32_t own_off = slot_[r] * 512;
             const i64 pb = G_.ptr[r], ne = G_.ptr[r + 1] - pb;
             const i64 ng = std::max<i64>(1, (ne + 3) / 4);
+            const size_t first_rec = P_.groups.size();
             for (i64 g = 0; g < ng; ++g) {
                 GroupRec rec;
                 const i64 cnt = std::max<i64>(0, std::min<i64>(4, ne - 4 * g));
-                for (i64 e = 0; e < 4; ++e) {
-                    if (e < cnt) {
-                        rec.off[e] = slot_[G_.idx[pb + 4 * g + e]] * 512;
-                        rec.coef[e] = G_.val[pb + 4 * g + e];
-                    } else {
-                        rec.off[e] = own_off;
-                        rec.coef[e] = 0.0;
-                    }
-                }
-                rec.rdiag = 1.0 / G_.diag[r];
+                for (i64 e = 0; e < 4; ++e) rec.off[e] = e < cnt ? slot_[G_.idx[pb + 4 * g + e]] * 512 : own_off;
                 rec.own_off = own_off;
                 rec.flags = (int32_t)cnt | (g == 0 ? GroupRec::kFirst : 0) | (g == ng - 1 ? GroupRec::kLast : 0);
                 P_.groups.push_back(rec);
             }
+            fill_group_values(G_, r, P_.groups.data() + first_rec);
             avail_[r] = (int32_t)level;
             task_of_[r] = -2;
             P_.cluster_entries += ne;
@@ -434,11 +506,33 @@ class Builder {
         }
     }
 
+    // ---- refill recipe (BlockProgram::Refill): a source code beside every value that is written -----------------
+    // (only for gather forms that keep their value sources: nobody can refill the others)
+    void grow_coef(size_t new_size)
+    {
+        P_.coef.resize(new_size, 0.0);
+        if (recipe_ok_) P_.refill.coef_src.resize(new_size, -1);
+    }
+    void set_code(size_t at, int32_t code)
+    {
+        if (code < 0 || !recipe_ok_) return;
+        int32_t &c = P_.refill.coef_src[at];
+        if (c != -1) recipe_ok_ = false;  // two values add up in one slot (duplicate entries of the matrix)
+        c = code;
+    }
+    int32_t diag_code(i64 r) const { return (int32_t)((i64)G_.idx.size() + r); }
+    int32_t pool_code(i64 at) const
+    {
+        const i64 c = (i64)G_.idx.size() + n_ + at;
+        return c < INT32_MAX ? (int32_t)c : -1;  // (run() invalidates the recipe when the pool does not fit)
+    }
+
     // ---- low-level emission ------------------------------------------------------------------------
     // sources: triples sorted by (pos, slot); ids of sources given by id_of(pos).  Returns block index.
+    // tri / tri_code: the block's own 16-stride triangle and the codes of its entries (refill recipe), or null.
     template <class IdOf>
     i64 push_block(int rows, const int32_t *dest, const int32_t *init, std::vector<Triple> &src, IdOf id_of, const double *tri,
-                   i64 level, bool own_task)
+                   const int32_t *tri_code, i64 level, bool own_task)
     {
         // distinct sources in ascending pos order.  Long lists (the rows of a supernode share their sources) are not
         // sorted as triples: the distinct positions are collected through the stamp array, sorted alone (an order of
@@ -474,50 +568,56 @@ class Builder {
         const size_t cbase = P_.coef.size();
         if (ranked) {
             for (int32_t pos : order_) P_.src_idx.push_back(id_of(pos));
-            P_.coef.resize(cbase + (size_t)distinct * rc, 0.0);
-            for (const Triple &x : src) P_.coef[cbase + (size_t)rank_[x.pos] * rc + x.slot] += x.val;  // duplicates add up
+            grow_coef(cbase + (size_t)distinct * rc);
+            for (const Triple &x : src) {
+                const size_t at = cbase + (size_t)rank_[x.pos] * rc + x.slot;
+                P_.coef[at] += x.val;  // duplicates add up
+                set_code(at, x.code);
+            }
         } else {
             for (size_t k = 0; k < src.size();) {
                 const int32_t pos = src[k].pos;
                 P_.src_idx.push_back(id_of(pos));
                 const size_t base = P_.coef.size();
-                P_.coef.resize(base + rc, 0.0);
-                for (; k < src.size() && src[k].pos == pos; ++k) P_.coef[base + src[k].slot] += src[k].val;  // duplicates add up
+                grow_coef(base + rc);
+                for (; k < src.size() && src[k].pos == pos; ++k) {
+                    P_.coef[base + src[k].slot] += src[k].val;  // duplicates add up
+                    set_code(base + src[k].slot, src[k].code);
+                }
             }
         }
         if (rc == 16 && ns > 0)  // the matrix-core path consumes sources sixteen at a time: pad with zero coefficients
             for (; ns % 16 != 0; ++ns) {
                 P_.src_idx.push_back(P_.src_idx.back());
-                P_.coef.resize(P_.coef.size() + rc, 0.0);
+                grow_coef(P_.coef.size() + rc);
             }
         h.nsrc = (int32_t)ns;
         P_.hdr.push_back(h);
         if (tri && rc < 16) {
             const size_t base = P_.coef.size();
-            P_.coef.resize(base + (size_t)rc * rc, 0.0);
+            grow_coef(base + (size_t)rc * rc);
             for (int r = 0; r < rc; ++r)
-                for (int t = 0; t <= r; ++t) P_.coef[base + (size_t)r * rc + t] = (r < rows) ? tri[r * 16 + t] : (t == r ? 1.0 : 0.0);
+                for (int t = 0; t <= r; ++t) {
+                    P_.coef[base + (size_t)r * rc + t] = (r < rows) ? tri[r * 16 + t] : (t == r ? 1.0 : 0.0);
+                    if (r < rows && tri_code) set_code(base + (size_t)r * rc + t, tri_code[r * 16 + t]);
+                }
         } else if (tri) {
-            // inverse of the block's 16 x 16 lower triangle (unit rows for padding), stored in the A-operand order of
-            // v_mfma_f64_16x16x4_f64: K-step k, lane l holds Tinv[l & 15][4k + (l >> 4)]
-            double T[16][16], Ti[16][16];
+            // inverse of the block's 16 x 16 lower triangle (unit rows for padding), in matrix-core order
+            double T[16][16];
             for (int r = 0; r < 16; ++r)
-                for (int t = 0; t < 16; ++t) {
-                    T[r][t] = (r < rows && t <= r) ? tri[r * 16 + t] : (t == r ? 1.0 : 0.0);
-                    Ti[r][t] = 0.0;
-                }
-            for (int c = 0; c < 16; ++c) {
-                Ti[c][c] = 1.0 / T[c][c];
-                for (int r = c + 1; r < 16; ++r) {
-                    double sum = 0.0;
-                    for (int t = c; t < r; ++t) sum += T[r][t] * Ti[t][c];
-                    Ti[r][c] = -sum / T[r][r];
-                }
-            }
+                for (int t = 0; t < 16; ++t) T[r][t] = (r < rows && t <= r) ? tri[r * 16 + t] : (t == r ? 1.0 : 0.0);
             const size_t base = P_.coef.size();
-            P_.coef.resize(base + 256, 0.0);
-            for (int k = 0; k < 4; ++k)
-                for (int l = 0; l < 64; ++l) P_.coef[base + (size_t)k * 64 + l] = Ti[l & 15][4 * k + (l >> 4)];
+            grow_coef(base + 256);
+            store_tri16_inverse(T, P_.coef.data() + base);
+            if (!tri_code) recipe_ok_ = false;
+            if (recipe_ok_) {
+                BlockProgram::Refill::Tri16 rec;
+                rec.coef_base = (i64)base;
+                rec.rows = rows;
+                for (int r = 0; r < 16; ++r)
+                    for (int t = 0; t <= r; ++t) rec.src[r * (r + 1) / 2 + t] = r < rows ? tri_code[r * 16 + t] : -1;
+                P_.refill.tri16.push_back(rec);
+            }
         }
         P_.padded_entries += ns * rc;
         if (own_task) {
@@ -580,7 +680,9 @@ class Builder {
         const int rows = (int)(b - a);
         int32_t dest[16];
         double tri[256];
+        int32_t tri_code[256];
         std::memset(tri, 0, sizeof(tri));
+        std::fill(tri_code, tri_code + 256, -1);
         src_.clear();
         i64 need = 0;
         bool chained = false;
@@ -589,13 +691,16 @@ class Builder {
             const int slot = (int)(t - a);
             dest[slot] = (int32_t)r;
             tri[slot * 16 + slot] = G_.diag[r];
+            tri_code[slot * 16 + slot] = diag_code(r);
             for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
                 const i64 s = G_.idx[p];
                 const i64 ps = pos_of(s);
                 if (ps >= a) {
                     tri[slot * 16 + (ps - a)] += G_.val[p];
+                    if (tri_code[slot * 16 + (ps - a)] != -1) recipe_ok_ = false;  // duplicate entries add up
+                    tri_code[slot * 16 + (ps - a)] = (int32_t)p;
                 } else {
-                    src_.push_back(Triple{(int32_t)ps, slot, G_.val[p]});
+                    src_.push_back(Triple{(int32_t)ps, slot, G_.val[p], (int32_t)p});
                     if (cur_task_ >= 0 && task_of_[s] == cur_task_) chained = true;
                     else need = std::max<i64>(need, avail_[s] + 1);
                 }
@@ -619,7 +724,7 @@ class Builder {
             task_nblk_.push_back(1);
         }
         const i64 keep_task = cur_task_;
-        push_block(rows, dest, dest, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, tri, level, false);
+        push_block(rows, dest, dest, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, tri, tri_code, level, false);
         cur_task_ = keep_task;
         for (i64 t = a; t < b; ++t) {
             avail_[row_at(t)] = (int32_t)level;
@@ -660,7 +765,7 @@ class Builder {
             for (size_t k = 0; k < src.size(); ++k) ns += (k == 0 || src[k].pos != src[k - 1].pos);
         }
         if (ns <= max_block_sources_) {
-            push_block(rows, dest, init, src, id_of, nullptr, level, true);
+            push_block(rows, dest, init, src, id_of, nullptr, nullptr, level, true);
             return level;
         }
         const i64 parts = (ns + max_block_sources_ - 1) / max_block_sources_;
@@ -700,14 +805,14 @@ class Builder {
                 pdest[(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
                 none[r] = kNone;
             }
-            push_block(rows, &pdest[(size_t)p * rows], p == 0 ? init : none, chunks[p], id_of, nullptr, level, true);
+            push_block(rows, &pdest[(size_t)p * rows], p == 0 ? init : none, chunks[p], id_of, nullptr, nullptr, level, true);
         }
         // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial)
         std::vector<Triple> comb;
         for (i64 p = 1; p < parts; ++p)
             for (int r = 0; r < rows; ++r) comb.push_back(Triple{(int32_t)((p - 1) * rows + r), r, -1.0});
         const int32_t *p1 = pdest.data() + rows;
-        push_block(rows, dest, pdest.data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, level + 1, true);
+        push_block(rows, dest, pdest.data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, nullptr, level + 1, true);
         return level + 1;
     }
 
@@ -720,42 +825,11 @@ class Builder {
         P_.big_chains++;
         P_.inverted_rows += w;
         // dense diagonal block in position coordinates, then its inverse (forward substitution per column)
-        std::vector<double> M((size_t)w * w, 0.0);
-        for (i64 t = t0; t < t1; ++t) {
-            const i64 r = row_at(t);
-            M[(size_t)(t - t0) * w + (t - t0)] = G_.diag[r];
-            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
-                const i64 ps = pos_of(G_.idx[p]);
-                if (ps >= t0) M[(size_t)(t - t0) * w + (ps - t0)] += G_.val[p];
-            }
-        }
-        ck.lap(3);
-        // every column of the inverse is an independent forward substitution: columns are dealt round-robin to the
-        // host threads (column c costs (w - c)^2 / 2, so interleaving balances them); the result does not depend on
-        // the number of threads
-        std::vector<double> Minv((size_t)w * w, 0.0);
-        auto invert_columns = [&](i64 first, i64 stride) {
-            std::vector<double> z(w);
-            for (i64 c = first; c < w; c += stride) {
-                z[c] = 1.0 / M[(size_t)c * w + c];
-                for (i64 r = c + 1; r < w; ++r) {
-                    const double *Mr = &M[(size_t)r * w];
-                    double s = 0.0;
-                    for (i64 t = c; t < r; ++t) s += Mr[t] * z[t];
-                    z[r] = -s / Mr[r];
-                }
-                for (i64 r = c; r < w; ++r) Minv[(size_t)r * w + c] = z[r];
-            }
-        };
-        // starting a thread costs tens of microseconds: only chains whose inverse takes milliseconds are shared out
-        const i64 nthreads = w >= 384 ? std::min<i64>(host_threads(), w / 64) : 1;
-        if (nthreads <= 1) {
-            invert_columns(0, 1);
-        } else {
-            std::vector<std::thread> pool;
-            for (i64 k = 0; k < nthreads; ++k) pool.emplace_back(invert_columns, k, nthreads);
-            for (std::thread &th : pool) th.join();
-        }
+        std::vector<double> Minv;
+        chain_inverse(G_, t0, t1, Minv);
+        const i64 pool_off = P_.refill.pool_size;
+        P_.refill.chains.push_back(BlockProgram::Refill::Chain{t0, t1, pool_off});
+        P_.refill.pool_size += w * w;
         ck.lap(4);
         const i64 y0 = P_.scratch_rows;
         P_.scratch_rows += w;
@@ -776,7 +850,7 @@ class Builder {
                     const i64 s = G_.idx[p];
                     const i64 ps = pos_of(s);
                     if (ps >= t0) continue;
-                    src_.push_back(Triple{(int32_t)ps, slot, G_.val[p]});
+                    src_.push_back(Triple{(int32_t)ps, slot, G_.val[p], (int32_t)p});
                     need = std::max<i64>(need, avail_[s] + 1);
                 }
             }
@@ -798,7 +872,8 @@ class Builder {
             }
             // generated in (source, slot) order: the sorts downstream see sorted input and skip
             for (i64 u = 0; u < b - t0; ++u)
-                for (i64 t = std::max(a, t0 + u); t < b; ++t) src_.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u]});
+                for (i64 t = std::max(a, t0 + u); t < b; ++t)
+                    src_.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u], pool_code(pool_off + (t - t0) * w + u)});
             const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
             final_level = std::max(final_level, done);
         }
@@ -864,7 +939,7 @@ class Builder {
         P_.hdr.swap(hdr);
         // the kernels fetch ids, coefficients and the triangle speculatively (clamped lane offsets): keep those in bounds
         P_.src_idx.resize(P_.src_idx.size() + 128, 0);
-        P_.coef.resize(P_.coef.size() + 320, 0.0);
+        grow_coef(P_.coef.size() + 320);
         // prologue records (sparse.hpp), in block order
         {
             constexpr int LW = BlockProgram::kLineWords;
@@ -935,10 +1010,69 @@ class Builder {
     std::vector<i64> task_first_blk_, task_nblk_;
     std::vector<int32_t> task_level_;
     i64 cur_task_ = -1;
+    bool recipe_ok_;
     StageClock clock_;
 };
 
 }  // namespace
+
+bool refill_block_program(const GatherForm &G, BlockProgram &P)
+{
+    const BlockProgram::Refill &R = P.refill;
+    if (!R.valid || R.coef_src.size() != P.coef.size()) return false;
+    const i64 n = G.n, nnz = (i64)G.idx.size();
+    // chain inverses: the large ones one after the other (each shares its columns out over the host threads), the many
+    // small ones side by side
+    std::vector<double> pool((size_t)R.pool_size);
+    {
+        std::vector<double> Minv;
+        for (const BlockProgram::Refill::Chain &c : R.chains)
+            if (c.t1 - c.t0 >= 384) {
+                chain_inverse(G, c.t0, c.t1, Minv);
+                std::copy(Minv.begin(), Minv.end(), pool.begin() + c.pool_off);
+            }
+    }
+    parallel_ranges((i64)R.chains.size(), 4, [&](i64 lo, i64 hi) {
+        std::vector<double> Minv;
+        for (i64 k = lo; k < hi; ++k) {
+            const BlockProgram::Refill::Chain &c = R.chains[k];
+            if (c.t1 - c.t0 >= 384) continue;
+            chain_inverse(G, c.t0, c.t1, Minv);
+            std::copy(Minv.begin(), Minv.end(), pool.begin() + c.pool_off);
+        }
+    });
+    auto value = [&](int32_t code) {
+        return code < nnz ? G.val[code] : code < nnz + n ? G.diag[code - nnz] : -pool[(size_t)(code - nnz - n)];
+    };
+    parallel_ranges((i64)R.coef_src.size(), 1 << 18, [&](i64 lo, i64 hi) {
+        for (i64 e = lo; e < hi; ++e)
+            if (R.coef_src[e] >= 0) P.coef[e] = value(R.coef_src[e]);
+    });
+    parallel_ranges((i64)R.tri16.size(), 256, [&](i64 lo, i64 hi) {
+        for (i64 k = lo; k < hi; ++k) {
+            const BlockProgram::Refill::Tri16 &t = R.tri16[k];
+            double T[16][16];
+            for (int r = 0; r < 16; ++r)
+                for (int c = 0; c < 16; ++c) {
+                    const int32_t code = c <= r ? t.src[r * (r + 1) / 2 + c] : -1;
+                    T[r][c] = (r < t.rows && c <= r) ? (code >= 0 ? value(code) : 0.0) : (c == r ? 1.0 : 0.0);
+                }
+            store_tri16_inverse(T, P.coef.data() + t.coef_base);
+        }
+    });
+    parallel_ranges((i64)R.clusters.size(), 256, [&](i64 lo, i64 hi) {
+        for (i64 c = lo; c < hi; ++c) {
+            const BlockProgram::Refill::Cluster &cl = R.clusters[c];
+            GroupRec *rec = P.groups.data() + cl.grp_off;
+            for (i64 k = 0; k <= cl.hi - cl.lo; ++k) {
+                const i64 r = G.descending ? cl.hi - k : cl.lo + k;
+                fill_group_values(G, r, rec);
+                rec += std::max<i64>(1, (G.ptr[r + 1] - G.ptr[r] + 3) / 4);
+            }
+        }
+    });
+    return true;
+}
 
 BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots, bool dense)
 {

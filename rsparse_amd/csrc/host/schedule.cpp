@@ -41,7 +41,8 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
     G.idx.resize(nz);
     G.val.assign(nz, 0.0);
     G.src.clear();
-    if (pattern_only) G.src.resize(nz);
+    const bool want_src = pattern_only || G.keep_src;
+    if (want_src) G.src.resize(nz);
     std::vector<i64> fill(G.ptr.begin(), G.ptr.end() - 1);
     // visit source columns in the order the reference's loop visits them, so each unknown accumulates its terms
     // in the reference's order: ascending j for lsolve/utsolve, descending j for ltsolve/usolve
@@ -52,8 +53,8 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
             const i64 i = T.i[p];
             const i64 q = fill[by_rows ? i : j]++;
             G.idx[q] = (int32_t)(by_rows ? j : i);
-            if (pattern_only) G.src[q] = (int32_t)p;
-            else G.val[q] = T.x[p];
+            if (want_src) G.src[q] = (int32_t)p;
+            if (!pattern_only) G.val[q] = T.x[p];
         }
     }
     return kOk;
@@ -67,7 +68,7 @@ void fill_gather_values(const CscView &T, int kind, GatherForm &G)
     parallel_ranges((i64)G.src.size(), 1 << 18, [&](i64 lo, i64 hi) {
         for (i64 q = lo; q < hi; ++q) G.val[q] = x[G.src[q]];
     });
-    std::vector<int32_t>().swap(G.src);
+    if (!G.keep_src) std::vector<int32_t>().swap(G.src);
 }
 
 Schedule build_schedule(const GatherForm &G, i64 max_task_entries)

@@ -94,6 +94,8 @@ struct GatherForm {
     std::vector<double> val;
     std::vector<double> diag;  // n
     std::vector<int32_t> src;  // pattern-only build: position in T.x of each entry, until fill_gather_values()
+    bool keep_src = false;     // true: src is recorded by every build and survives fill_gather_values(), so that new values
+                               // of the same pattern can be poured in again (refactorisation)
 };
 // kind: 0 lsolve, 1 ltsolve, 2 usolve, 3 utsolve (include/rsparse_hip.h rsp_tri_kind). Returns kOk or kBadInput.
 // T.x == nullptr builds the pattern only (val and diag stay zero, src remembers where every value will come from).
@@ -211,7 +213,31 @@ struct BlockProgram {
     std::vector<i64> cluster_level_ptr;  // clusters of level l (same level numbering)
     i64 scratch_rows = 0;
     i64 big_chains = 0, inverted_rows = 0, padded_entries = 0, cluster_rows = 0, cluster_entries = 0;
+    // REFILL RECIPE: where every value of the programme comes from, so that new values on the same pattern (a
+    // refactorisation) are poured into coef and groups without emitting the programme again (refill_block_program).
+    // A source code is -1 (a constant: padding, the -1 of a partial-sum combine), an entry of the gather form
+    // [0, nnz): G.val[code], a diagonal [nnz, nnz + n): G.diag[code - nnz], or an entry of a chain inverse
+    // [nnz + n, ...): -pool[code - nnz - n].  valid == false (duplicate entries that add up, dense tasks, more than 2^31
+    // codes): the programme is emitted again instead.
+    struct Refill {
+        bool valid = false;
+        std::vector<int32_t> coef_src;  // one code per entry of coef
+        struct Tri16 {                  // a 16 x 16 block triangle whose INVERSE is stored (matrix-core order) at coef_base
+            i64 coef_base;
+            int32_t rows;
+            int32_t src[136];           // code of T[r][t], t <= r, at r (r + 1) / 2 + t
+        };
+        std::vector<Tri16> tri16;
+        struct Chain { i64 t0, t1, pool_off; };  // positions [t0, t1) inverted as one dense triangle into pool
+        std::vector<Chain> chains;
+        i64 pool_size = 0;
+        struct Cluster { i64 lo, hi, grp_off; };  // unknowns [lo, hi] and the first group record, in emission order
+        std::vector<Cluster> clusters;
+    } refill;
 };
+// new values (G refilled by fill_gather_values) into the coef and groups of a programme built from the same pattern;
+// false if the programme carries no valid recipe
+bool refill_block_program(const GatherForm &G, BlockProgram &P);
 constexpr i64 kBigChain = 24;        // chains longer than this are replaced by their inverse
 constexpr i64 kMaxChain = 1024;      // ... in pieces of at most this many unknowns (host cost O(w^3) per piece)
 constexpr i64 kSplitSources = 64;    // matrix-core blocks with at least this many sources are split over 4 wavefronts,

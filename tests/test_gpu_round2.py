@@ -241,6 +241,54 @@ def test_chol_refactor_twice_vs_oracle():
         F.refactor(synth.circuit_spd(n + 1, 6, 100))  # another size: bad input
 
 
+@pytest.mark.parametrize("matrix", ["circuit", "grid"])
+@pytest.mark.parametrize("refill", ["device", "host", "rebuild"])
+def test_refactor_keeps_or_rebuilds_the_solve_programmes(refill, matrix, monkeypatch):
+    """After rsp_chol_refactor_f64 the resident solve programmes receive the new values in place -- by kernels straight
+    from the factor on the device (default), or on the host through the same recipe (RSP_REFILL_DEVICE=0) -- or are
+    analysed and emitted again (RSP_REFILL=0): wide, narrow and single right-hand sides against the oracle every way,
+    and the launch summary of the programmes does not change.  "grid" is a 2-D mesh whose separators become chains that
+    are replaced by their inverses (widths that are no multiples of 64), "circuit" has none."""
+    if refill == "host":
+        monkeypatch.setenv("RSP_REFILL_DEVICE", "0")
+    if refill == "rebuild":
+        monkeypatch.setenv("RSP_REFILL", "0")
+    if matrix == "circuit":
+        n = 2600
+        mats = [synth.circuit_spd(n, 6, 300 + s) for s in range(3)]
+    else:
+        base = synth.laplacian_2d(150, 131)
+        n = base[0]
+        mats = []
+        for s in range(3):  # same pattern, other values: scaled, and the diagonal pushed up unevenly
+            m, nn, p, i, x = base
+            x2 = x * (1.0 + 0.5 * s)
+            diag = np.asarray(i, np.int64) == np.repeat(np.arange(nn), np.diff(p))
+            x2[diag] += 0.3 * s * synth.splitmix64(400 + s, nn)
+            mats.append((m, nn, p, i, x2))
+    F = rs.CholHandle(mats[0], rs.schol(mats[0], 0))
+    B = np.asfortranarray((2.0 * synth.splitmix64(301, n * 40) - 1.0).reshape(n, 40))
+    first_info = None
+    for k, A in enumerate(mats + [mats[1]]):
+        if k:
+            F.refactor(A)
+        X = B.copy(order="F")
+        F.solve(X)                       # 40 columns: the blocked programme, 64-column wavefronts
+        x1 = B[:, 3].copy()
+        F.solve(x1)                      # one column: 16-column wavefronts on the same programme
+        for c in (0, 3, 39):
+            st, want = orc.cholsol(A, B[:, c].copy(), 0)
+            assert st == orc.OK and rel_inf(X[:, c], want) <= REL_X, (k, c)
+        assert rel_inf(x1, orc.cholsol(A, B[:, 3].copy(), 0)[1]) <= REL_X
+        fi = F.info()
+        keys = ("lsolve_launches", "lsolve_tasks", "ltsolve_launches", "ltsolve_tasks")
+        if first_info is None:
+            first_info = [fi[key] for key in keys]
+            assert all(v > 0 for v in first_info)
+        else:
+            assert [fi[key] for key in keys] == first_info
+
+
 def test_factor_view_is_the_resident_factor():
     """rsp_chol_factor_view: the host pattern and the device values the solves read, without a copy; equal to
     rsp_chol_get_factor's copy, and it follows a refactor."""

@@ -417,3 +417,51 @@ def test_qr_rejects_foreign_symbolic():
         ra.qr(A, ra.schol(A, 0))            # a Cholesky analysis: no QR row permutation
     with pytest.raises(ra.DeviceError):
         ra.qr(A, ra.sqr(load_sprs("cholsol_2.sprs"), 2, True))  # another matrix
+
+
+# ---- refill of a programme with new values on the same pattern (refactorisation) ----
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "lu_L", "lu_U", "band"])
+def test_programme_refill_is_bitwise_a_fresh_emission(case):
+    """New values poured into a programme through its recipe == the programme emitted from scratch for those values, bit
+    for bit (coefficients, 16 x 16 triangle inverses, chain inverses, cluster records), for every solve kind that applies;
+    several builder settings (small clusters, several blocks per task)."""
+    import rsparse_amd as ra
+    from rsparse_amd import synth
+    from oracle import pyoracle as orc
+    if case in ("lap2d", "lap3d"):
+        A = synth.laplacian_2d(60, 47) if case == "lap2d" else synth.laplacian_3d(12)
+        st, T = orc.chol(A, orc.schol(A, 0))
+        kinds = (0, 1)
+    elif case in ("lu_L", "lu_U"):
+        st, f = orc.lu(synth.banded_unsymmetric(1800, band=30), 1, 1.0)
+        T, kinds = (f["L"], (0, 1)) if case == "lu_L" else (f["U"], (2, 3))
+    else:  # a dense band: long chains (inverses in pieces) and source lists cut into partial sums
+        n, p, i, x = 1400, [0], [], []
+        for j in range(n):
+            rows = list(range(j, min(n, j + 1101)))
+            i += rows
+            x += [4.0 + j % 3] + [0.01 * ((r * 7 + j) % 11 - 5) for r in rows[1:]]
+            p.append(len(i))
+        T, st, kinds = (n, n, np.array(p), np.array(i), np.array(x)), 0, (0, 1)
+    assert st == 0
+    nz = int(T[2][-1])
+    new_values = np.asarray(T[4][:nz]) * (1.0 + 0.3 * synth.splitmix64(9, nz))
+    for kind in kinds:
+        for opts in ({}, {"cluster_slots": 8}, {"task_blocks": 3}):
+            r = ra.validate_refill(T, new_values, kind, **opts)
+            assert r["has_recipe"] == 1 and r["coef_mismatches"] == 0 and r["group_mismatches"] == 0 and r["coef_entries"] > 0, (kind, opts, r)
+
+
+def test_programme_without_recipe_is_reported():
+    """Duplicate entries add up inside one coefficient: such a programme carries no recipe (and is emitted again)."""
+    import rsparse_amd as ra
+    p, i, x = [0], [], []
+    for j in range(60):
+        i.append(j)
+        x.append(2.0)
+        if j + 1 < 60:
+            i += [j + 1, j + 1]
+            x += [0.1, 0.2]
+        p.append(len(i))
+    r = ra.validate_refill((60, 60, np.array(p), np.array(i), np.array(x)), np.array(x) * 1.5, 0)
+    assert r["has_recipe"] == 0
