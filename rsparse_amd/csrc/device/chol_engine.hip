@@ -54,7 +54,14 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
         const double c = (double)(Lp_[j + 1] - Lp_[j]);
         flops_ += c * c;
     }
-    if (single_use && lnz_ < INT32_MAX) {
+    // A handle that will solve many times: its two solve programmes depend on the pattern alone as well, so they are
+    // emitted beside this analysis and the factorisation too (placeholder values), and the factor's values reach them on
+    // the device at the first solve (TriSolver::refresh_device) -- L never visits the host.
+    const auto off = [](const char *name) { return getenv(name) && getenv(name)[0] == '0'; };
+    const auto on = [](const char *name, char v) { return getenv(name) && getenv(name)[0] == v; };
+    pat_ahead_ = !single_use && !off("RSP_REFILL") && !off("RSP_REFILL_DEVICE") && !off("RSP_PROGRAMME_AHEAD") && !on("RSP_TRI_SINGLE", '1') &&
+                 !on("RSP_TRI_BLOCKED", '0');
+    if ((single_use || pat_ahead_) && lnz_ < INT32_MAX) {
         // the solve phase needs the level structure of L in both directions, which depends on the pattern alone: start it
         // now, beside the rest of this analysis and the factorisation (Lp_ and Li_ do not change any more)
         pat_lower_.reset(new TriSolver);
@@ -63,7 +70,10 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
             pat_thread_[k] = std::thread([this, k] {
                 try {
                     const CscView Lpat{n_, n_, Lp_.data(), Li_.data(), nullptr};
-                    pat_status_[k] = (k == 0 ? pat_lower_ : pat_upper_)->analyze(Lpat, k);
+                    TriSolver &t = *(k == 0 ? pat_lower_ : pat_upper_);
+                    if (pat_ahead_) t.keep_for_refill();
+                    pat_status_[k] = t.analyze(Lpat, k);
+                    if (pat_ahead_ && pat_status_[k] == kOk) t.stage_blocked_pattern();
                 } catch (...) {
                     pat_status_[k] = kBadInput;  // build_solvers() falls back to the full analysis
                 }
@@ -639,6 +649,23 @@ void CholFactor::build_solvers()
             return;
         }
     }
+    if (pat_ahead_ && pat_lower_ && pat_upper_ && pat_status_[0] == kOk && pat_status_[1] == kOk) {
+        // the programmes were emitted beside the factorisation: upload them and pour the factor in, all on the device
+        std::unique_ptr<TriSolver> lo = std::move(pat_lower_), up = std::move(pat_upper_);
+        pat_ahead_ = false;
+        const CscView Lpat{n_, n_, Lp_.data(), Li_.data(), nullptr};
+        if (lo->adopt_staged() && up->adopt_staged() && lo->refresh_device(Lpat, d_Lx.get(), nullptr) &&
+            up->refresh_device(Lpat, d_Lx.get(), nullptr)) {
+            RSP_HIP(hipStreamSynchronize(nullptr));
+            lower_ = std::move(lo);
+            upper_ = std::move(up);
+            solvers_stale_ = false;
+            if (getenv("RSP_TIMING")) fprintf(stderr, "chol solvers: programmes emitted ahead, upload + values on the device %.3fs\n", now_s() - t0);
+            return;
+        }
+        // (anything else -- another engine selected, no recipe -- takes the full analysis with the values on the host)
+    }
+    pat_ahead_ = false;
     std::vector<double> Lx((size_t)lnz_);
     d_Lx.download(Lx.data(), Lx.size());
     const CscView L{n_, n_, Lp_.data(), Li_.data(), Lx.data()};

@@ -93,6 +93,7 @@ class CholFactor {
     DeviceBuffer<double> d_dbuf;  // parked diagonal blocks of tall panels (fused levels)
     // batched solve phase: CSR index of L and the level sets of both sweeps
     i64 batch_ = 1;
+    bool pat_ahead_ = false;  // the pattern jobs also emit the blocked programmes (values follow on the device)
     bool solvers_stale_ = false;  // refactorised since the solve programmes received their values
     int32_t nlev_l_ = 0, nlev_t_ = 0;
     DeviceBuffer<int32_t> d_Li32, d_row_ptr, d_row_col, d_row_pos, d_lev_ptr_l, d_lev_rows_l, d_lev_ptr_t, d_lev_cols_t;

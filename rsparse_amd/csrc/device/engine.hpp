@@ -227,6 +227,12 @@ class TriSolver {
     // of the gather form keeps the OLD values afterwards: the plain level programmes cannot be built from it any more
     // (DeviceError) until a refresh_host.
     bool refresh_device(const CscView &T, const double *dTx, hipStream_t stream);
+    // PROGRAMME AHEAD OF THE VALUES: after a pattern-only analyze() (keep_for_refill() on), emit the blocked programme with
+    // placeholder values -- host work, any thread, e.g. beside a numeric factorisation that is still running.  Every
+    // value in it is rewritten by refresh_device() before the first solve; adopt_staged() uploads it (false: nothing
+    // usable was staged, e.g. the supernodal engine is selected).
+    void stage_blocked_pattern();
+    bool adopt_staged();
     void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
                     double *scratch_override = nullptr);
     // Row-major solve that allocates nothing: the blocked programme must already be resident (one earlier solve through

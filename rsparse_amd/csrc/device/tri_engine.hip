@@ -421,6 +421,24 @@ void TriSolver::build_blocked()
     }
 }
 
+void TriSolver::stage_blocked_pattern()
+{
+    if (G_.src.empty() || env_or("RSP_SUPERNODAL", kSupernodal) != 0 || env_or("RSP_DENSE_TASKS", kDenseTasks) != 0) return;
+    sn_decided_ = true;  // (the blocked engine: the supernodal one is off)
+    use_sn_ = false;
+    staged_.reset(new BlockProgram(build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots), false)));
+    if (!staged_->refill.valid) staged_.reset();
+    host_values_stale_ = true;  // the gather form holds no values at all yet
+}
+
+bool TriSolver::adopt_staged()
+{
+    if (!staged_ || have_blocked_ || have_sn_) return false;
+    build_blocked();
+    have_blocked_ = true;
+    return kept_ != nullptr;
+}
+
 bool TriSolver::refresh_host(const CscView &T)
 {
     if (!have_blocked_ || !kept_ || G_.src.empty() || T.n != n_ || T.nnz() + 0 != (i64)G_.src.size() + n_) return false;
