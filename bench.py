@@ -58,6 +58,31 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
+CHOL_SOURCES = ("device/chol_kernels.hip", "device/chol_engine.hip", "device/chol_engine.hpp")
+
+
+def chol_sha():
+    h = hashlib.sha256()
+    for f in CHOL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "rsparse_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_chol_traffic():
+    """HBM bytes of one numeric factorisation at C2 from the committed --pmc passes (profiles/*chol*_summary.json, made by
+    tools/collect_chol_profile.py), or None when the profile was measured on other Cholesky sources."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_chol_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("chol_sha") == chol_sha():
+                best = (int(d["traffic"]["hbm_bytes_per_factorisation"]), d["tag"])
+        except Exception:
+            pass
+    return best
+
+
 def measured_traffic(cfg):
     """HBM bytes of one step from the committed rocprofv3 --pmc passes (profiles/*_summary.json, made by
     tools/pmc.sh + tools/collect_profiles.py on this same command), with the profile's tag -- or (None, None) when no
@@ -252,7 +277,9 @@ def main():
             roofline_chol = {"bound": "mfma", "achieved": fi["flops"] / t_meas / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
         else:
             roofline_chol = {"bound": "hbm", "achieved": fi["bytes_chol"] / t_meas / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
-        roofline_chol.update({"frac": roofline_chol["achieved"] / roofline_chol["peak"], "traffic": None, "ms": fi["factor_ms"],
+        chol_traffic = measured_chol_traffic() if args.config == "c2" else None
+        roofline_chol.update({"frac": roofline_chol["achieved"] / roofline_chol["peak"], "traffic": chol_traffic[0] if chol_traffic else None,
+                              "traffic_profile": chol_traffic[1] if chol_traffic else None, "ms": fi["factor_ms"],
                               "bytes": fi["bytes_chol"], "flops": fi["flops"],
                               "kernel": "chol_panel_factor + chol_tile_update + chol_tiny_panels: one numeric factorisation"})
         del F
