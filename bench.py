@@ -20,6 +20,7 @@ Other modes (parity/bench lines of their own, never the headline):
 refuses to run when --gpus disagrees with WORLD_SIZE.
 """
 import argparse
+import glob
 import hashlib
 import json
 import os
@@ -88,7 +89,6 @@ def measured_traffic(cfg):
     tools/pmc.sh + tools/collect_profiles.py on this same command), with the profile's tag -- or (None, None) when no
     pass matches this configuration (same matrix, right-hand sides, programme) AND these kernel sources: counters
     cannot be read from inside the timed process, and a profile of older kernels says nothing about these."""
-    import glob
     keys = ("n", "nnz_L", "nrhs_per_gpu", "lsolve_tasks", "lsolve_launches", "ltsolve_launches")
     best, tag, sha = None, None, kernels_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
