@@ -66,14 +66,20 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
         // now, beside the rest of this analysis and the factorisation (Lp_ and Li_ do not change any more)
         pat_lower_.reset(new TriSolver);
         pat_upper_.reset(new TriSolver);
+        int device = 0;
+        RSP_HIP(hipGetDevice(&device));
         for (int k = 0; k < 2; ++k)
-            pat_thread_[k] = std::thread([this, k] {
+            pat_thread_[k] = std::thread([this, k, device] {
                 try {
                     const CscView Lpat{n_, n_, Lp_.data(), Li_.data(), nullptr};
                     TriSolver &t = *(k == 0 ? pat_lower_ : pat_upper_);
                     if (pat_ahead_) t.keep_for_refill();
                     pat_status_[k] = t.analyze(Lpat, k);
-                    if (pat_ahead_ && pat_status_[k] == kOk) t.stage_blocked_pattern();
+                    if (pat_ahead_ && pat_status_[k] == kOk) {
+                        t.stage_blocked_pattern();
+                        // ... and sends it to the device right away: the first solve finds it there
+                        if (hipSetDevice(device) == hipSuccess && t.adopt_staged()) t.prepare_refresh_device(Lpat);
+                    }
                 } catch (...) {
                     pat_status_[k] = kBadInput;  // build_solvers() falls back to the full analysis
                 }

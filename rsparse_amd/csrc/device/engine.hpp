@@ -233,6 +233,11 @@ class TriSolver {
     // usable was staged, e.g. the supernodal engine is selected).
     void stage_blocked_pattern();
     bool adopt_staged();
+    // sends the recipe to the device ahead of the first refresh_device (which would do it otherwise); T: the pattern
+    void prepare_refresh_device(const CscView &T)
+    {
+        if (have_blocked_ && kept_ && !recipe_.built) build_device_recipe(T);
+    }
     void run_window(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
                     double *scratch_override = nullptr);
     // Row-major solve that allocates nothing: the blocked programme must already be resident (one earlier solve through

@@ -433,7 +433,8 @@ void TriSolver::stage_blocked_pattern()
 
 bool TriSolver::adopt_staged()
 {
-    if (!staged_ || have_blocked_ || have_sn_) return false;
+    if (have_blocked_) return kept_ != nullptr;  // already uploaded
+    if (!staged_ || have_sn_) return false;
     build_blocked();
     have_blocked_ = true;
     return kept_ != nullptr;

@@ -41,6 +41,7 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
     G.idx.resize(nz);
     G.val.assign(nz, 0.0);
     G.src.clear();
+    G.placeholder = pattern_only;
     const bool want_src = pattern_only || G.keep_src;
     if (want_src) G.src.resize(nz);
     std::vector<i64> fill(G.ptr.begin(), G.ptr.end() - 1);
@@ -69,6 +70,7 @@ void fill_gather_values(const CscView &T, int kind, GatherForm &G)
         for (i64 q = lo; q < hi; ++q) G.val[q] = x[G.src[q]];
     });
     if (!G.keep_src) std::vector<int32_t>().swap(G.src);
+    G.placeholder = false;
 }
 
 Schedule build_schedule(const GatherForm &G, i64 max_task_entries)

@@ -94,6 +94,7 @@ struct GatherForm {
     std::vector<double> val;
     std::vector<double> diag;  // n
     std::vector<int32_t> src;  // pattern-only build: position in T.x of each entry, until fill_gather_values()
+    bool placeholder = false;  // a pattern-only build whose values have not been filled in yet (val and diag are zeros)
     bool keep_src = false;     // true: src is recorded by every build and survives fill_gather_values(), so that new values
                                // of the same pattern can be poured in again (refactorisation)
 };

@@ -4,7 +4,8 @@ os.environ["RSP_TIMING"] = "1"
 sys.path.insert(0, '.')
 import rsparse_amd as rs
 from rsparse_amd import synth
-A = synth.laplacian_2d(1024); n = A[0]
+arg = sys.argv[1] if len(sys.argv) > 1 else '1024'
+A = synth.laplacian_3d(int(arg[2:])) if arg.startswith('3d') else synth.laplacian_2d(int(arg)); n = A[0]
 F = rs.CholHandle(A, rs.schol(A, 0))
 X = torch.rand(n, 256, dtype=torch.float64, device='cuda')
 st = torch.cuda.current_stream().cuda_stream
