@@ -118,6 +118,11 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
  * entries or an oversized inverse pool -- such programmes are always emitted again), report[1] = coefficient entries that
  * differ, report[2] = cluster records that differ, report[3] = coefficient entries. */
 int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int kind, int64_t task_blocks, int cluster_slots, int64_t *report);
+/* Host-only fingerprint of the programme built for T (debug aid, no GPU): FNV-1a hashes of out[0] its pattern (headers,
+ * ids, prologue records, task and level tables), out[1] its coefficients, out[2] its clusters and group records,
+ * out[3] its refill recipe.  The tests use it to show that the programme does not depend on how many host threads
+ * emitted it. */
+int rsp_tri_program_checksum(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, uint64_t *out);
 
 /* The same for the SUPERNODAL programme (dense LDS tasks at the bottom of the forest, supernode products above; debug aid,
  * host only, no reference counterpart).  options (may be NULL) = {task slots (< 0: no tasks), widest node with folded

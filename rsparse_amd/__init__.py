@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     Sprs,
     Symb,
     TriHandle,
+    program_checksum,
     validate_program,
     validate_refill,
     validate_supernodal,

@@ -70,6 +70,7 @@ def lib():
             "rsp_tri_free": (None, [vp]),
             "rsp_tri_validate_program": (cint, [csc, cint, i64, cint, vp, vp]),
             "rsp_tri_validate_refill": (cint, [csc, vp, cint, i64, cint, vp]),
+            "rsp_tri_program_checksum": (cint, [csc, cint, i64, cint, vp]),
             "rsp_tri_validate_supernodal": (cint, [csc, cint, vp, vp, vp]),
             "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
@@ -546,6 +547,14 @@ def validate_refill(t, new_values, kind, task_blocks=0, cluster_slots=0):
     rep = np.zeros(4, np.int64)
     _check(lib().rsp_tri_validate_refill(C.byref(t._view()), v.ctypes.data, kind, task_blocks, cluster_slots, rep.ctypes.data))
     return dict(zip(("has_recipe", "coef_mismatches", "group_mismatches", "coef_entries"), rep.tolist()))
+
+
+def program_checksum(t, kind, task_blocks=0, cluster_slots=0):
+    """Host-only fingerprint (four 64-bit hashes) of the multi-RHS programme built for `t` (rsp_tri_program_checksum)."""
+    t = _as_sprs(t)
+    out = np.zeros(4, np.uint64)
+    _check(lib().rsp_tri_program_checksum(C.byref(t._view()), kind, task_blocks, cluster_slots, out.ctypes.data))
+    return tuple(int(v) for v in out)
 
 
 def validate_supernodal(t, kind, task_slots=0, small_node=0, max_node=0, max_item_k=0):

@@ -345,6 +345,31 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
     });
 }
 
+int rsp_tri_program_checksum(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, uint64_t *out)
+{
+    if (!sane(T) || !out) return RSP_BAD_INPUT;
+    return guarded([&] {
+        GatherForm G;
+        G.keep_src = true;
+        if (int st = build_gather_form(view_of(T), kind, G)) return st;
+        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, cluster_slots > 0 ? cluster_slots : kClusterSlots, false);
+        auto fnv = [](const void *data, size_t bytes) {
+            uint64_t h = 1469598103934665603ull;
+            const unsigned char *p = static_cast<const unsigned char *>(data);
+            for (size_t k = 0; k < bytes; ++k) h = (h ^ p[k]) * 1099511628211ull;
+            return h;
+        };
+        out[0] = fnv(P.hdr.data(), P.hdr.size() * sizeof(BlockHeader)) ^ fnv(P.src_idx.data(), P.src_idx.size() * 4) ^
+                 fnv(P.prologue.data(), P.prologue.size() * 4) ^ fnv(P.task_ptr.data(), P.task_ptr.size() * 8) ^
+                 fnv(P.level_class_ptr.data(), P.level_class_ptr.size() * 8);
+        out[1] = fnv(P.coef.data(), P.coef.size() * 8);
+        out[2] = fnv(P.groups.data(), P.groups.size() * sizeof(GroupRec)) ^ fnv(P.clusters.data(), P.clusters.size() * sizeof(ClusterHeader)) ^
+                 fnv(P.cluster_ids.data(), P.cluster_ids.size() * 4);
+        out[3] = fnv(P.refill.coef_src.data(), P.refill.coef_src.size() * 4) ^ (uint64_t)P.scratch_rows ^ ((uint64_t)P.refill.pool_size << 20);
+        return (int)RSP_OK;
+    });
+}
+
 int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int kind, int64_t task_blocks, int cluster_slots, int64_t *report)
 {
     if (!sane(T) || !new_values || !report) return RSP_BAD_INPUT;

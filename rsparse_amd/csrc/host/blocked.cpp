@@ -146,6 +146,8 @@ class Builder {
         tune("RSP_BIG_CHAIN", big_chain_);
         tune("RSP_MAX_BLOCK_SOURCES", max_block_sources_);
         if (const char *e = std::getenv("RSP_DENSE_FILL")) dense_fill_ = std::atof(e);
+        emit_threads_ = host_threads();  // RSP_EMIT_THREADS=0: the sequential path (the programme does not depend on it)
+        tune("RSP_EMIT_THREADS", emit_threads_);
     }
 
     BlockProgram run()
@@ -752,6 +754,110 @@ class Builder {
         return k;
     }
 
+    // ---- the same blocks from sources that are ALREADY RANKED (long chains: the ranking of a group of rows is a pure
+    //      function of the gather form, done on the host threads; only these appends are sequential) -----------------
+    struct RankedGroup {
+        int rows = 0;
+        int32_t dest[16], init[16];
+        std::vector<Triple> src;     // pos = rank of the source among the group's distinct sources; by part when parts > 1
+        std::vector<int32_t> order;  // the distinct sources, ascending: what id_of() is asked for
+        std::vector<i64> part_off;   // parts + 1 offsets into src
+        i64 need = 0, parts = 1, per = 0;
+    };
+
+    // one block of its own task, no triangle: exactly what push_block(.., nullptr, nullptr, level, true) appends for the
+    // sources order[0, distinct) and the triples src[0, nsrc) whose ranks start at rank_base
+    template <class IdOf>
+    void append_block(int rows, const int32_t *dest, const int32_t *init, const int32_t *order, i64 distinct, const Triple *src, size_t nsrc,
+                      int32_t rank_base, IdOf id_of, i64 level)
+    {
+        const int rc = distinct >= split_sources_ ? 16 : class_of(rows);
+        const i64 b = (i64)P_.hdr.size();
+        BlockHeader h{rc, 0, 0, 0, (i64)P_.src_idx.size(), (i64)P_.coef.size()};
+        for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? dest[r] : kNone);
+        for (int r = 0; r < rc; ++r) P_.src_idx.push_back(r < rows ? init[r] : kNone);
+        i64 ns = distinct;
+        const size_t cbase = P_.coef.size();
+        for (i64 k = 0; k < distinct; ++k) P_.src_idx.push_back(id_of(order[k]));
+        grow_coef(cbase + (size_t)distinct * rc);
+        for (size_t k = 0; k < nsrc; ++k) {
+            const size_t at = cbase + (size_t)(src[k].pos - rank_base) * rc + src[k].slot;
+            P_.coef[at] += src[k].val;  // duplicates add up
+            set_code(at, src[k].code);
+        }
+        if (rc == 16 && ns > 0)
+            for (; ns % 16 != 0; ++ns) {
+                P_.src_idx.push_back(P_.src_idx.back());
+                grow_coef(P_.coef.size() + rc);
+            }
+        h.nsrc = (int32_t)ns;
+        P_.hdr.push_back(h);
+        P_.padded_entries += ns * rc;
+        close_task();
+        task_first_blk_.push_back(b);
+        task_level_.push_back((int32_t)level);
+        task_nblk_.push_back(1);
+    }
+
+    // distinct sources and ranks of a group's triples (pos = processing position on entry, rank on return), cut into
+    // parts of at most max_block_sources_ sources; scratch: a stamp and a rank per unknown, private to the calling thread
+    void rank_group(RankedGroup &g, std::vector<i64> &stamp, i64 &stamp_id, std::vector<int32_t> &rank) const
+    {
+        ++stamp_id;
+        g.order.clear();
+        for (const Triple &x : g.src)
+            if (stamp[x.pos] != stamp_id) {
+                stamp[x.pos] = stamp_id;
+                g.order.push_back(x.pos);
+            }
+        std::sort(g.order.begin(), g.order.end());
+        for (size_t k = 0; k < g.order.size(); ++k) rank[g.order[k]] = (int32_t)k;
+        for (Triple &x : g.src) x.pos = rank[x.pos];
+        const i64 ns = (i64)g.order.size();
+        g.parts = ns <= max_block_sources_ ? 1 : (ns + max_block_sources_ - 1) / max_block_sources_;
+        g.per = (ns + g.parts - 1) / g.parts;
+        g.part_off.clear();
+        if (g.parts > 1) {  // counting sort by part, the order inside a part kept
+            g.part_off.assign((size_t)g.parts + 1, 0);
+            for (const Triple &x : g.src) g.part_off[(size_t)(x.pos / g.per) + 1]++;
+            for (i64 p = 0; p < g.parts; ++p) g.part_off[p + 1] += g.part_off[p];
+            std::vector<i64> fill(g.part_off.begin(), g.part_off.end() - 1);
+            std::vector<Triple> sorted(g.src.size());
+            for (const Triple &x : g.src) sorted[(size_t)fill[(size_t)(x.pos / g.per)]++] = x;
+            g.src.swap(sorted);
+        }
+    }
+
+    // emit_gather for a ranked group (the same blocks, scratch rows and levels)
+    template <class IdOf>
+    i64 emit_gather_ranked(const RankedGroup &g, IdOf id_of, i64 level)
+    {
+        const i64 ns = (i64)g.order.size();
+        if (g.parts == 1) {
+            append_block(g.rows, g.dest, g.init, g.order.data(), ns, g.src.data(), g.src.size(), 0, id_of, level);
+            return level;
+        }
+        const int rows = g.rows;
+        std::vector<int32_t> pdest((size_t)g.parts * rows);
+        for (i64 p = 0; p < g.parts; ++p) {
+            int32_t none[16];
+            for (int r = 0; r < rows; ++r) {
+                pdest[(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
+                none[r] = kNone;
+            }
+            const i64 first = p * g.per, cnt = std::min(g.per, ns - first);
+            append_block(rows, &pdest[(size_t)p * rows], p == 0 ? g.init : none, g.order.data() + first, cnt, g.src.data() + g.part_off[p],
+                         (size_t)(g.part_off[p + 1] - g.part_off[p]), (int32_t)first, id_of, level);
+        }
+        // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial)
+        std::vector<Triple> comb;
+        for (i64 p = 1; p < g.parts; ++p)
+            for (int r = 0; r < rows; ++r) comb.push_back(Triple{(int32_t)((p - 1) * rows + r), r, -1.0});
+        const int32_t *p1 = pdest.data() + rows;
+        push_block(rows, g.dest, pdest.data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, nullptr, level + 1, true);
+        return level + 1;
+    }
+
     // ---- gather into dest with the source list cut into partial sums of at most kMaxBlockSources sources ----------
     // src triples: pos = ordinal understood by id_of.  Every block is its own task.  Returns the level at which dest
     // is complete.
@@ -841,6 +947,64 @@ class Builder {
         P_.scratch_rows += w;
         // phase A per group of 16 unknowns: all groups independent
         i64 ready = 0;
+        if (emit_threads_ > 0) {
+            // the triples of a group, its distinct sources and their ranks are a pure function of the gather form (and of
+            // avail_, which this chain does not change before its end): batches of groups are prepared on the host
+            // threads, then appended in order -- the programme is the same as from the sequential path below
+            const i64 ngroups = (w + 15) / 16;
+            const i64 T = std::max<i64>(1, std::min<i64>(emit_threads_, ngroups));
+            if ((i64)tstamp_.size() < T) {
+                tstamp_.resize((size_t)T);
+                trank_.resize((size_t)T);
+                tstamp_id_.resize((size_t)T, 0);
+            }
+            const i64 batch = 4 * T;
+            std::vector<RankedGroup> work((size_t)std::min(batch, ngroups));
+            for (i64 g0 = 0; g0 < ngroups; g0 += batch) {
+                const i64 g1 = std::min(ngroups, g0 + batch);
+                auto prepare = [&](i64 k) {
+                    if (tstamp_[k].empty()) {
+                        tstamp_[k].assign(n_, -1);
+                        trank_[k].assign(n_, 0);
+                    }
+                    for (i64 g = g0 + k; g < g1; g += T) {
+                        RankedGroup &G = work[(size_t)(g - g0)];
+                        const i64 a = t0 + 16 * g, b = std::min(a + 16, t1);
+                        G.rows = (int)(b - a);
+                        G.src.clear();
+                        G.need = 0;
+                        for (i64 t = a; t < b; ++t) {
+                            const i64 r = row_at(t);
+                            const int slot = (int)(t - a);
+                            G.dest[slot] = ~(int32_t)(y0 + (t - t0));
+                            G.init[slot] = (int32_t)r;
+                            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                                const i64 s = G_.idx[p];
+                                const i64 ps = pos_of(s);
+                                if (ps >= t0) continue;
+                                G.src.push_back(Triple{(int32_t)ps, slot, G_.val[p], (int32_t)p});
+                                G.need = std::max<i64>(G.need, avail_[s] + 1);
+                            }
+                        }
+                        rank_group(G, tstamp_[k], tstamp_id_[k], trank_[k]);
+                    }
+                };
+                if (T == 1) {
+                    prepare(0);
+                } else {
+                    std::vector<std::thread> pool;
+                    for (i64 k = 1; k < T; ++k) pool.emplace_back(prepare, k);
+                    prepare(0);
+                    for (std::thread &th : pool) th.join();
+                }
+                ck.lap(5);
+                for (i64 g = g0; g < g1; ++g) {
+                    const i64 done = emit_gather_ranked(work[(size_t)(g - g0)], [&](int32_t pos) { return (int32_t)row_at(pos); }, work[(size_t)(g - g0)].need);
+                    ready = std::max(ready, done);
+                }
+                ck.lap(6);
+            }
+        } else
         for (i64 a = t0; a < t1; a += 16) {
             const i64 b = std::min(a + 16, t1);
             const int rows = (int)(b - a);
@@ -876,11 +1040,35 @@ class Builder {
                 dest[t - a] = (int32_t)row_at(t);
                 init[t - a] = kNone;
             }
-            // generated in (source, slot) order: the sorts downstream see sorted input and skip
-            for (i64 u = 0; u < b - t0; ++u)
-                for (i64 t = std::max(a, t0 + u); t < b; ++t)
-                    src_.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u], pool_code(pool_off + (t - t0) * w + u)});
-            const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
+            i64 done;
+            if (emit_threads_ > 0) {
+                // the sources are the scratch rows 0 .. b - t0 - 1, every one of them used: a source's rank is its number, and
+                // triples generated source by source are already grouped by part
+                RankedGroup &G = chain_group_;
+                G.rows = rows;
+                std::copy(dest, dest + 16, G.dest);
+                std::copy(init, init + 16, G.init);
+                const i64 ns = b - t0;
+                G.order.resize((size_t)ns);
+                for (i64 u = 0; u < ns; ++u) G.order[(size_t)u] = (int32_t)u;
+                G.parts = ns <= max_block_sources_ ? 1 : (ns + max_block_sources_ - 1) / max_block_sources_;
+                G.per = (ns + G.parts - 1) / G.parts;
+                G.src.clear();
+                G.part_off.assign((size_t)G.parts + 1, 0);
+                for (i64 u = 0; u < ns; ++u) {
+                    for (i64 t = std::max(a, t0 + u); t < b; ++t)
+                        G.src.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u], pool_code(pool_off + (t - t0) * w + u)});
+                    G.part_off[(size_t)(u / G.per) + 1] = (i64)G.src.size();
+                }
+                for (i64 p = 0; p < G.parts; ++p) G.part_off[p + 1] = std::max(G.part_off[p + 1], G.part_off[p]);
+                done = emit_gather_ranked(G, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
+            } else {
+                // generated in (source, slot) order: the sorts downstream see sorted input and skip
+                for (i64 u = 0; u < b - t0; ++u)
+                    for (i64 t = std::max(a, t0 + u); t < b; ++t)
+                        src_.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u], pool_code(pool_off + (t - t0) * w + u)});
+                done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
+            }
             final_level = std::max(final_level, done);
         }
         for (i64 t = t0; t < t1; ++t) {
@@ -1009,6 +1197,12 @@ class Builder {
     i64 stamp_id_ = 0, run_id_ = 0;
     std::vector<Triple> src_;
     std::vector<int32_t> order_, rank_;  // push_block: distinct source positions and their ranks
+    // emit_big_chain: private scratch of the threads that rank the groups of a chain
+    i64 emit_threads_ = 0;
+    RankedGroup chain_group_;
+    std::vector<std::vector<i64>> tstamp_;
+    std::vector<std::vector<int32_t>> trank_;
+    std::vector<i64> tstamp_id_;
     std::vector<i64> cluster_lo_, cluster_hi_;
     std::vector<int32_t> cluster_level_;  // in emission order
     std::vector<int32_t> emit_order_;     // emission order -> cluster id (index into cluster_lo_)

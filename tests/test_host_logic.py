@@ -465,3 +465,34 @@ def test_programme_without_recipe_is_reported():
         p.append(len(i))
     r = ra.validate_refill((60, 60, np.array(p), np.array(i), np.array(x)), np.array(x) * 1.5, 0)
     assert r["has_recipe"] == 0
+
+
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "lu_U"])
+def test_programme_does_not_depend_on_emitter_threads(case, monkeypatch):
+    """The groups of a long chain are ranked on the host threads and appended in order: the programme (pattern,
+    coefficients, clusters, recipe) is bit for bit the one the sequential emitter writes, for any number of threads and
+    with small part / split thresholds (partial sums everywhere)."""
+    import rsparse_amd as ra
+    from rsparse_amd import synth
+    from oracle import pyoracle as orc
+    if case == "lap2d":
+        A = synth.laplacian_2d(140, 121)
+        st, T = orc.chol(A, orc.schol(A, 0))
+        kinds = (0, 1)
+    elif case == "lap3d":
+        A = synth.laplacian_3d(13)
+        st, T = orc.chol(A, orc.schol(A, 0))
+        kinds = (0, 1)
+    else:
+        st, f = orc.lu(synth.banded_unsymmetric(2000, band=36), 1, 1.0)
+        T, kinds = f["U"], (2, 3)
+    assert st == 0
+    for env in ({}, {"RSP_MAX_BLOCK_SOURCES": "96", "RSP_SPLIT_SOURCES": "32"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for kind in kinds:
+            sums = []
+            for threads in ("0", "1", "5", "16"):
+                monkeypatch.setenv("RSP_EMIT_THREADS", threads)
+                sums.append(ra.program_checksum(T, kind))
+            assert all(s == sums[0] for s in sums), (case, kind, env)
