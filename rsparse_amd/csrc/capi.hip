@@ -839,6 +839,7 @@ static int cholsol_batch_on_device(const rsp_csc_f64 *A, const double *Ax_all, d
         const int64_t n = A->n, nnz = A->p[n];
         const Symbolic S = symbolic_cholesky(view_of(A), order);  // one ordering and one analysis for the whole batch
         CholFactor F;
+        if (n <= kBatchMaxN) F.no_solve_programmes();  // the batch is solved out of LDS, straight from the factors
         if (int st = F.analyze(view_of(A), S)) return st;
         bool any_bad = false;
         std::vector<int32_t> bad;

@@ -59,7 +59,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
     // the device at the first solve (TriSolver::refresh_device) -- L never visits the host.
     const auto off = [](const char *name) { return getenv(name) && getenv(name)[0] == '0'; };
     const auto on = [](const char *name, char v) { return getenv(name) && getenv(name)[0] == v; };
-    pat_ahead_ = !single_use && !off("RSP_REFILL") && !off("RSP_REFILL_DEVICE") && !off("RSP_PROGRAMME_AHEAD") && !on("RSP_TRI_SINGLE", '1') &&
+    pat_ahead_ = want_programmes_ && !single_use && !off("RSP_REFILL") && !off("RSP_REFILL_DEVICE") && !off("RSP_PROGRAMME_AHEAD") && !on("RSP_TRI_SINGLE", '1') &&
                  !on("RSP_TRI_BLOCKED", '0');
     if ((single_use || pat_ahead_) && lnz_ < INT32_MAX) {
         // the solve phase needs the level structure of L in both directions, which depends on the pattern alone: start it

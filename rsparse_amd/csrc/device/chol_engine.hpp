@@ -50,6 +50,8 @@ class CholFactor {
     const double *device_Lx() const { return d_Lx.get(); }
     // the factor is solved against once and discarded (cholsol): see TriSolver::set_single_use()
     void set_single_use(bool v) { single_use_ = v; }
+    // before analyze(): this factor's solves never go through the solve programmes (the batched LDS solve): do not emit them
+    void no_solve_programmes() { want_programmes_ = false; }
 
    private:
     void build_solvers();
@@ -93,6 +95,7 @@ class CholFactor {
     DeviceBuffer<double> d_dbuf;  // parked diagonal blocks of tall panels (fused levels)
     // batched solve phase: CSR index of L and the level sets of both sweeps
     i64 batch_ = 1;
+    bool want_programmes_ = true;
     bool pat_ahead_ = false;  // the pattern jobs also emit the blocked programmes (values follow on the device)
     bool solvers_stale_ = false;  // refactorised since the solve programmes received their values
     int32_t nlev_l_ = 0, nlev_t_ = 0;
