@@ -59,7 +59,9 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
-CHOL_SOURCES = ("device/chol_kernels.hip", "device/chol_engine.hip", "device/chol_engine.hpp")
+# the factorisation kernels (chol_engine.* also holds the solve-phase plumbing of a handle, which changes more often and
+# does not move the factorisation's traffic)
+CHOL_SOURCES = ("device/chol_kernels.hip",)
 
 
 def chol_sha():
