@@ -4,12 +4,18 @@
 // encoded here is exactly the order those loops impose.
 #include <algorithm>
 #include <limits>
+#include <thread>
 
 #include "parallel.hpp"
 #include "sparse.hpp"
 
 namespace rsp {
 
+// The columns of T are cut into one contiguous piece of the VISITING order per host thread (ascending j for lsolve /
+// utsolve, descending for ltsolve / usolve -- the order in which the reference's loop meets the entries).  Thread k
+// counts its entries per unknown, the counts become (unknown, thread) offsets, and every thread then writes its entries
+// behind those of the threads that visit earlier columns: every unknown keeps its terms in the reference's order, and
+// the result does not depend on the number of threads.
 int build_gather_form(const CscView &T, int kind, GatherForm &G)
 {
     const i64 n = T.n;
@@ -22,19 +28,58 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
     G.descending = (kind == 1 || kind == 2);
     G.diag.assign(n, 0.0);
     G.ptr.assign(n + 1, 0);
-    // validate + diagonal + per-unknown entry counts
-    for (i64 j = 0; j < n; ++j) {
-        const i64 b = T.p[j], e = T.p[j + 1];
-        if (e <= b || b < 0 || e > T.nnz()) return kBadInput;  // the reference indexes the diagonal unconditionally
-        const i64 dpos = lower_storage ? b : e - 1;
-        if (!pattern_only) G.diag[j] = T.x[dpos];
-        for (i64 p = (lower_storage ? b + 1 : b); p < (lower_storage ? e : e - 1); ++p) {
-            const i64 i = T.i[p];
-            // off-diagonal entries must lie strictly inside the triangle, otherwise the loops of the reference
-            // do not describe a triangular solve (it would silently compute something else)
-            if (lower_storage ? !(i > j && i < n) : !(i >= 0 && i < j)) return kBadInput;
-            G.ptr[(by_rows ? i : j) + 1]++;
+    const i64 threads = std::max<i64>(1, std::min<i64>(host_threads(), T.nnz() >> 18));
+    auto piece = [&](i64 k, i64 &lo, i64 &hi) {  // positions [lo, hi) of the visiting order
+        lo = n * k / threads;
+        hi = n * (k + 1) / threads;
+    };
+    auto run = [&](auto &&body) {
+        std::vector<std::thread> pool;
+        for (i64 k = 1; k < threads; ++k) pool.emplace_back(body, k);
+        body((i64)0);
+        for (std::thread &th : pool) th.join();
+    };
+    // validate + diagonal + entry counts per (unknown, thread)
+    std::vector<std::vector<int32_t>> count((size_t)threads);
+    std::vector<char> bad((size_t)threads, 0);
+    run([&](i64 k) {
+        if (by_rows && threads > 1) count[k].assign(n, 0);
+        i64 lo, hi;
+        piece(k, lo, hi);
+        for (i64 t = lo; t < hi; ++t) {
+            const i64 j = G.descending ? n - 1 - t : t;
+            const i64 b = T.p[j], e = T.p[j + 1];
+            if (e <= b || b < 0 || e > T.nnz()) {  // the reference indexes the diagonal unconditionally
+                bad[k] = 1;
+                return;
+            }
+            const i64 dpos = lower_storage ? b : e - 1;
+            if (!pattern_only) G.diag[j] = T.x[dpos];
+            const i64 first = lower_storage ? b + 1 : b, last = lower_storage ? e : e - 1;
+            for (i64 p = first; p < last; ++p) {
+                const i64 i = T.i[p];
+                // off-diagonal entries must lie strictly inside the triangle, otherwise the loops of the reference
+                // do not describe a triangular solve (it would silently compute something else)
+                if (lower_storage ? !(i > j && i < n) : !(i >= 0 && i < j)) {
+                    bad[k] = 1;
+                    return;
+                }
+                if (by_rows && threads > 1) count[k][i]++;
+                else if (by_rows) G.ptr[i + 1]++;
+            }
+            if (!by_rows) G.ptr[j + 1] = last - first;
         }
+    });
+    for (char b : bad)
+        if (b) return kBadInput;
+    if (by_rows && threads > 1) {
+        parallel_ranges(n, 1 << 16, [&](i64 lo, i64 hi) {
+            for (i64 r = lo; r < hi; ++r) {
+                i64 total = 0;
+                for (i64 k = 0; k < threads; ++k) total += count[k][r];
+                G.ptr[r + 1] = total;
+            }
+        });
     }
     for (i64 r = 0; r < n; ++r) G.ptr[r + 1] += G.ptr[r];
     const i64 nz = G.ptr[n];
@@ -44,20 +89,39 @@ int build_gather_form(const CscView &T, int kind, GatherForm &G)
     G.placeholder = pattern_only;
     const bool want_src = pattern_only || G.keep_src;
     if (want_src) G.src.resize(nz);
-    std::vector<i64> fill(G.ptr.begin(), G.ptr.end() - 1);
+    if (by_rows && threads > 1) {
+        // count[k][r] becomes the first slot of thread k in unknown r (threads in visiting order)
+        parallel_ranges(n, 1 << 16, [&](i64 lo, i64 hi) {
+            for (i64 r = lo; r < hi; ++r) {
+                i64 at = G.ptr[r];
+                for (i64 k = 0; k < threads; ++k) {
+                    const int32_t c = count[k][r];
+                    count[k][r] = (int32_t)at;
+                    at += c;
+                }
+            }
+        });
+    }
+    std::vector<i64> fill;
+    if (by_rows && threads == 1) fill.assign(G.ptr.begin(), G.ptr.end() - 1);
     // visit source columns in the order the reference's loop visits them, so each unknown accumulates its terms
     // in the reference's order: ascending j for lsolve/utsolve, descending j for ltsolve/usolve
-    for (i64 t = 0; t < n; ++t) {
-        const i64 j = G.descending ? n - 1 - t : t;
-        const i64 b = T.p[j], e = T.p[j + 1];
-        for (i64 p = (lower_storage ? b + 1 : b); p < (lower_storage ? e : e - 1); ++p) {
-            const i64 i = T.i[p];
-            const i64 q = fill[by_rows ? i : j]++;
-            G.idx[q] = (int32_t)(by_rows ? j : i);
-            if (want_src) G.src[q] = (int32_t)p;
-            if (!pattern_only) G.val[q] = T.x[p];
+    run([&](i64 k) {
+        i64 lo, hi;
+        piece(k, lo, hi);
+        for (i64 t = lo; t < hi; ++t) {
+            const i64 j = G.descending ? n - 1 - t : t;
+            const i64 b = T.p[j], e = T.p[j + 1];
+            i64 own = G.ptr[j];
+            for (i64 p = (lower_storage ? b + 1 : b); p < (lower_storage ? e : e - 1); ++p) {
+                const i64 i = T.i[p];
+                const i64 q = !by_rows ? own++ : threads > 1 ? count[k][i]++ : fill[i]++;
+                G.idx[q] = (int32_t)(by_rows ? j : i);
+                if (want_src) G.src[q] = (int32_t)p;
+                if (!pattern_only) G.val[q] = T.x[p];
+            }
         }
-    }
+    });
     return kOk;
 }
 

@@ -496,3 +496,23 @@ def test_programme_does_not_depend_on_emitter_threads(case, monkeypatch):
                 monkeypatch.setenv("RSP_EMIT_THREADS", threads)
                 sums.append(ra.program_checksum(T, kind))
             assert all(s == sums[0] for s in sums), (case, kind, env)
+
+
+def test_gather_form_does_not_depend_on_host_threads(monkeypatch):
+    """The factor's columns are cut into pieces of the visiting order, one per host thread; every unknown still receives
+    its terms in the reference's order: programmes built from the gather form are bit-identical for 1, 3 and 8 threads
+    (a factor large enough for the threaded path: more than 2^19 entries per thread piece), all four solve kinds."""
+    import rsparse_amd as ra
+    from rsparse_amd import synth
+    from oracle import pyoracle as orc
+    A = synth.laplacian_2d(220, 220)
+    st, L = orc.chol(A, orc.schol(A, 0))
+    st2, f = orc.lu(synth.banded_unsymmetric(30000, band=40), 1, 1.0)
+    assert st == 0 and st2 == 0 and int(L[2][-1]) > 2 ** 20 and int(f["U"][2][-1]) > 2 ** 20
+    for T, kinds in ((L, (0, 1)), (f["U"], (2, 3))):
+        for kind in kinds:
+            sums = []
+            for threads in ("1", "3", "8"):
+                monkeypatch.setenv("RSP_HOST_THREADS", threads)
+                sums.append(ra.program_checksum(T, kind))
+            assert sums[0] == sums[1] == sums[2], kind
