@@ -97,8 +97,9 @@ int rsp_tri_solve_dev_noalloc_f64(rsp_tri *h, double *dX, int64_t ld, int64_t nr
  * at the top of one half's dependency tree run beside the other half's heavy levels.  Ordered after earlier work
  * on `stream`; later work on `stream` is ordered after both halves.  Not re-entrant per handle. */
 int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int64_t ld, int64_t nrhs, void *stream);
-/* info[0..8] = n, nnz, dependency levels of single unknowns, tasks, kernel launches per sweep, device bytes of the
- *              programme, algorithmic bytes for one sweep of 1 rhs, unknowns in inverted chains, scratch rows */
+/* info[0..10] = n, nnz, dependency levels of single unknowns, tasks, kernel launches per sweep, device bytes of the
+ *               programme, algorithmic bytes for one sweep of 1 rhs, unknowns in inverted chains, scratch rows, wide items
+ *               (64-row products over the chains' blocks), multiply-adds per right-hand side of the wide items */
 int rsp_tri_info(const rsp_tri *h, int64_t *info);
 /* integer schedule, for bit-exact comparison with the host oracle: level_of_row[n] */
 int rsp_tri_levels(const rsp_tri *h, int64_t *level_of_row);

@@ -599,9 +599,10 @@ class TriHandle:
         _check(lib().rsp_tri_solve_dev_noalloc_f64(self._h, ptr, ld, nrhs, stream))
 
     def info(self):
-        a = np.zeros(9, np.int64)
+        a = np.zeros(11, np.int64)
         _check(lib().rsp_tri_info(self._h, a.ctypes.data))
-        keys = ("n", "nnz", "row_levels", "tasks", "launches", "device_bytes", "bytes_1rhs", "inverted_rows", "scratch_rows")
+        keys = ("n", "nnz", "row_levels", "tasks", "launches", "device_bytes", "bytes_1rhs", "inverted_rows", "scratch_rows", "items",
+                "item_entries")
         return dict(zip(keys, a.tolist()))
 
     def levels(self):

@@ -265,6 +265,7 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
         info[6] = s.algorithmic_bytes(1);
         info[7] = 0;
         info[8] = Sp.scratch_rows;
+        info[9] = info[10] = 0;
         return RSP_OK;
     }
     info[3] = blocked ? Bp.ntasks : P.ntasks;
@@ -273,6 +274,8 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
     info[6] = s.algorithmic_bytes(1);
     info[7] = blocked ? Bp.inverted_rows : 0;
     info[8] = blocked ? Bp.scratch_rows : 0;
+    info[9] = blocked ? Bp.nitems : 0;
+    info[10] = blocked ? Bp.item_entries : 0;
     return RSP_OK;
 }
 
@@ -328,7 +331,15 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
         const bool dense = cluster_slots < 0 || (cluster_slots == 0 && kDenseTasks != 0);
         const int slots = cluster_slots > 0 ? cluster_slots : cluster_slots < 0 ? -cluster_slots : (dense ? kDenseSlots : kClusterSlots);
         const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, slots, dense);
-        const ProgramReport R = check_block_program(G, P);
+        // both views of the programme: the wide items as their twin blocks, and as items
+        ProgramReport R = check_block_program(G, P, false);
+        if (!P.items.empty()) {
+            const ProgramReport R2 = check_block_program(G, P, true);
+            R.bad_index += R2.bad_index;
+            R.order_violations += R2.order_violations;
+            R.unwritten += R2.unwritten;
+            if (!(R2.max_rel_error <= R.max_rel_error)) R.max_rel_error = R2.max_rel_error;
+        }
         report[0] = R.bad_index;
         report[1] = R.order_violations;
         report[2] = R.unwritten;
@@ -361,7 +372,8 @@ int rsp_tri_program_checksum(const rsp_csc_f64 *T, int kind, int64_t task_blocks
         };
         out[0] = fnv(P.hdr.data(), P.hdr.size() * sizeof(BlockHeader)) ^ fnv(P.src_idx.data(), P.src_idx.size() * 4) ^
                  fnv(P.prologue.data(), P.prologue.size() * 4) ^ fnv(P.task_ptr.data(), P.task_ptr.size() * 8) ^
-                 fnv(P.level_class_ptr.data(), P.level_class_ptr.size() * 8);
+                 fnv(P.level_class_ptr.data(), P.level_class_ptr.size() * 8) ^ fnv(P.items.data(), P.items.size() * sizeof(WideItem)) ^
+                 fnv(P.item_masks.data(), P.item_masks.size() * 4) ^ fnv(P.item_level_ptr.data(), P.item_level_ptr.size() * 8);
         out[1] = fnv(P.coef.data(), P.coef.size() * 8);
         out[2] = fnv(P.groups.data(), P.groups.size() * sizeof(GroupRec)) ^ fnv(P.clusters.data(), P.clusters.size() * sizeof(ClusterHeader)) ^
                  fnv(P.cluster_ids.data(), P.cluster_ids.size() * 4);
@@ -999,7 +1011,6 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
         N->lower->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
         N->upper->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
         RSP_HIP(hipDeviceSynchronize());
-        if (N->lower->merged_failed() || N->upper->merged_failed()) return (int)RSP_DEVICE_ERROR;
         d.download(x.data(), x.size());
         const int64_t *q = S->s.has_q ? S->s.q.data() : nullptr;
         for (int64_t r = 0; r < nrhs; ++r)

@@ -615,81 +615,5 @@ __global__ __launch_bounds__(512, LAT ? 2 : 4) void solve_level(BlockArrays B, L
     level_workgroup<FAST, LAT, NT>(B, L, item, w, red, X, ldx, S, lds, nrhs, nchunks, lane);
 }
 
-// SEVERAL CONSECUTIVE LEVELS IN ONE LAUNCH (narrow blocks: one right-hand side up to 16 columns, levels of a few
-// workgroups each, where a launch costs more than the level's work).  The workgroups of the run are numbered level by
-// level (no padding: wg_begin[l + 1] - wg_begin[l] is exactly what level l needs); a workgroup of level l first waits
-// until every workgroup of level l - 1 has published the launch's epoch in its flag word (they waited for level l - 2
-// before they finished, and so on), then runs exactly what solve_level would have run.
-// One flag word per workgroup, written once with a plain agent-scope store: a shared arrival counter was measured at
-// ~0.25 us per arrival (same-address atomics serialise), which made the merged launch 3x SLOWER than separate ones.
-// Progress: workgroups are dispatched in the order of their numbers (per XCD), so the unfinished workgroup with the
-// smallest number is always resident, and everything it waits for has finished.  As a second line of defence every wait
-// is BOUNDED: after kMergedSpinCap polls the workgroup raises `failed`, which makes every later workgroup of the launch
-// skip its work and leave; the host reports the solve as failed (RSP_DEVICE_ERROR) at its next synchronous point.
-// Visibility across XCDs (each has its own L2): every wavefront waits for its stores, the workgroup meets at a barrier,
-// and one lane publishes the flag with an agent-scope release (L2 write-back); the polling wavefront acquires at agent
-// scope (L1 and L2 invalidate) before the barrier that lets the other wavefronts of its workgroup go.
-struct MergedRun {
-    const LevelDesc *levels;
-    const int *wg_begin;  // nlevels + 1: first workgroup of each level
-    unsigned *flags;      // one word per workgroup of the run: the epoch of the last launch it finished in
-    unsigned *failed;     // sticky
-    int nlevels;
-    unsigned epoch;       // of this launch (never 0)
-};
-constexpr unsigned kMergedSpinCap = 1u << 20;  // x (sleep + one load): seconds
-constexpr int kMergedMaxLevelWorkgroups = 128;  // two flag words per lane of the polling wavefront
-
-template <bool FAST, bool LAT, int NT>
-__global__ __launch_bounds__(512, LAT ? 2 : 4) void solve_levels_merged(BlockArrays B, MergedRun M, double *X, int64_t ldx, double *S, int64_t lds,
-                                                                        int nrhs, int nchunks)
-{
-    extern __shared__ double red[];
-    __shared__ int skip;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wg = (int)blockIdx.x;
-    int lo = 0, hi = M.nlevels;  // level of this workgroup: wg_begin[lo] <= wg < wg_begin[lo + 1]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (M.wg_begin[mid] <= wg) lo = mid;
-        else hi = mid;
-    }
-    const int first = M.wg_begin[lo];
-    const LevelDesc L = M.levels[lo];
-    if (w == 0) {
-        int give_up = 0;
-        if (lo > 0) {
-            const int pfirst = M.wg_begin[lo - 1], need = first - pfirst;  // <= kMergedMaxLevelWorkgroups (host)
-            const unsigned *f0 = M.flags + pfirst + min(lane, need - 1), *f1 = M.flags + pfirst + min(lane + 64, need - 1);
-            unsigned polls = 0;
-            while (true) {
-                const bool ok = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == M.epoch &&
-                                (need <= 64 || __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == M.epoch);
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                __builtin_amdgcn_s_sleep(4);
-                if (++polls > kMergedSpinCap) {
-                    give_up = 1;
-                    break;
-                }
-            }
-        }
-        if (lane == 0) {
-            if (__hip_atomic_load(M.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) give_up = 1;
-            if (give_up) __hip_atomic_store(M.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            skip = give_up;
-        }
-        // one invalidate for the compute unit (its L1) and the XCD (its L2), ahead of the barrier that releases the other
-        // wavefronts: with an acquire in every wavefront a level cost 13 us instead of 9
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    const int dead = skip;  // the same value in every thread: the work below contains workgroup barriers
-    if (!dead) level_workgroup<FAST, LAT, NT>(B, L, wg - first, w, red, X, ldx, S, lds, nrhs, nchunks, lane);
-    __builtin_amdgcn_s_waitcnt(0);  // this wavefront's stores have been acknowledged by the L2 ...
-    __syncthreads();                // ... so the release below (one L2 write-back) carries the rows of all eight
-    if (threadIdx.x == 0) __hip_atomic_store(M.flags + wg, M.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 }  // namespace dev
 }  // namespace rsp

@@ -122,6 +122,9 @@ struct BlockedProgram {
     DeviceBuffer<int32_t> src_idx;
     DeviceBuffer<double> coef;
     DeviceBuffer<int32_t> prologue;
+    DeviceBuffer<WideItem> items;       // wide items (item_kernels.hip): the chains' blocks again, 64 rows at a time
+    DeviceBuffer<uint32_t> item_masks;
+    i64 nitems = 0, item_entries = 0;
     bool single_block_tasks = false;
     DeviceBuffer<ClusterHeader> clusters;
     DeviceBuffer<int32_t> cluster_ids;
@@ -131,18 +134,20 @@ struct BlockedProgram {
     DeviceBuffer<double> dense_coef;
     i64 dense_nodes = 0, dense_ksteps = 0;
     struct Level {
-        i64 task_begin[4];  // by class (BlockProgram::level_class_ptr)
-        int ntasks[4];
-        i64 block_begin[4];  // first block of each class (split classes: one block per task)
-        i64 rec_begin[4];  // prologue record of the first block of each class
+        i64 task_begin[BlockProgram::kClasses];  // by class (BlockProgram::level_class_ptr)
+        int ntasks[BlockProgram::kClasses];
+        i64 block_begin[BlockProgram::kClasses];  // first block of each class (split classes: one block per task)
+        i64 rec_begin[BlockProgram::kClasses];  // prologue record of the first block of each class
         i64 cluster_begin;
         int nclusters;
+        i64 item_begin;
+        int nitems, item_ksteps_max;
     };
     std::vector<Level> levels;
     size_t device_bytes() const
     {
         return task_ptr.bytes() + hdr.bytes() + prologue.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
-               groups.bytes() + dense_steps.bytes() + dense_coef.bytes();
+               groups.bytes() + dense_steps.bytes() + dense_coef.bytes() + items.bytes() + item_masks.bytes();
     }
 };
 
@@ -286,24 +291,6 @@ class TriSolver {
     DeviceBuffer<double> scratch_;  // scratch rows of the blocked programme (row-major, ld = nrhs)
     DeviceBuffer<double> work_;  // row-major staging for column-major callers
     i64 scratch_cols_ = 0;
-    // Narrow blocks (at most 16 columns): runs of consecutive levels whose only work is the block kernel go out as ONE
-    // launch each (solve_levels_merged).  Built on the first narrow solve; the level descriptors do not depend on the
-    // number of columns below 17.
-    struct MergedTables {
-        bool built = false;
-        i64 key = -1;                      // the launch thresholds the tables were built for
-        DeviceBuffer<char> levels;         // dev::LevelDesc of every level in a run, run after run
-        DeviceBuffer<int> wg_begin;        // per run: its levels' first workgroups, plus one
-        DeviceBuffer<unsigned> counters;   // one flag word per workgroup of every run, then one sticky failure word
-        unsigned epoch = 0;                // of the last merged launch
-        std::vector<int> run_at;           // per level of the programme: index of the run that STARTS there, else -1
-        struct Run { int first_level, nlevels, desc_off, wg_off, total_wgs, flag_off; };
-        std::vector<Run> runs;
-    } merged_;
-
-   public:
-    // true if a merged launch ever gave up waiting (sticky; the results of that solve are not valid).  Synchronises.
-    bool merged_failed();
 };
 
 // first.solve then second.solve on one row-major device block, column halves pipelined over two streams
@@ -315,7 +302,6 @@ void solve_pair_device(TriSolver &first, TriSolver &second, double *X_rowmajor, 
 // tunables (entries = off-diagonal nonzeros processed sequentially by one wavefront)
 constexpr i64 kTaskEntriesMulti = 2048;   // unblocked fallback programme
 constexpr i64 kTaskEntriesSingle = 512;
-constexpr i64 kMergedMinLevels = 2;  // shorter runs keep their plain launches
 constexpr i64 kLeanLaunchWorkgroups = 128;  // levels with at least this many 512-thread workgroups run the lean variant
 constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 right-hand sides: 3 parts are 2 % faster but re-read the
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)
@@ -325,6 +311,8 @@ constexpr i64 kSupernodalMaxLaunches = 300;
 constexpr i64 kDenseTasks = 0;   // 1: the bottom of the forest runs as dense LDS tasks (dense_kernels.hip), 0: as group-record clusters
 constexpr i64 kDenseNT = 1;      // 16-column tiles per wavefront of a dense task
 constexpr i64 kNoAllocScratchDoubles = 4 << 20;  // 32 MiB per GPU, held until the process ends (rsp_tri_solve_dev_noalloc_f64)
+constexpr i64 kItemLaunchWaves = 512;  // a level runs its wide items as items (dev::solve_items) from this many (item, 64 columns) pairs,
+                                       // as their twin 16-row blocks below it
 constexpr i64 kSmallLaunchWaves = 2048;  // small-block tasks of a level get their own launch from this many wavefronts
 
 }  // namespace rsp

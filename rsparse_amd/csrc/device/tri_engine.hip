@@ -11,6 +11,7 @@
 #include "engine.hpp"
 #include "solve_kernels.hip"
 #include "blocked_kernels.hip"
+#include "item_kernels.hip"
 #include "cluster_kernels.hip"
 #include "dense_kernels.hip"
 #include "sn_kernels.hip"
@@ -358,9 +359,15 @@ void TriSolver::build_blocked()
             lv.block_begin[c] = P.task_ptr[lv.task_begin[c]];
             lv.rec_begin[c] = P.block_record[lv.block_begin[c]];
         }
-        D.launches += (lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2] + lv.ntasks[3]) > 0;
+        int any = 0;
+        for (int c = 0; c < NC; ++c) any += lv.ntasks[c];
+        D.launches += any > 0;
         lv.cluster_begin = P.cluster_level_ptr[l];
         lv.nclusters = (int)(P.cluster_level_ptr[l + 1] - P.cluster_level_ptr[l]);
+        lv.item_begin = P.item_level_ptr[l];
+        lv.nitems = (int)(P.item_level_ptr[l + 1] - P.item_level_ptr[l]);
+        lv.item_ksteps_max = 0;
+        for (i64 k = P.item_level_ptr[l]; k < P.item_level_ptr[l + 1]; ++k) lv.item_ksteps_max = std::max(lv.item_ksteps_max, (int)P.items[k].k_steps);
         D.launches += lv.nclusters > 0;
         D.levels.push_back(lv);
     }
@@ -375,14 +382,19 @@ void TriSolver::build_blocked()
                     else { vec += (i64)h.nsrc * h.rc; ++vblk; }
                     for (int r = 0; r < h.rc; ++r) rows += P.src_idx[h.src_off + r] != BlockProgram::kNone;
                 }
-            fprintf(stderr, "L%lld tasks %d/%d/%d/%d blocks %lld rows %lld mfma_stages %lld max %lld vec_blocks %lld vec_entries %lld clusters %d\n",
-                    (long long)l, D.levels[l].ntasks[0], D.levels[l].ntasks[1], D.levels[l].ntasks[2], D.levels[l].ntasks[3], (long long)nb, (long long)rows,
-                    (long long)stages, (long long)maxst, (long long)vblk, (long long)vec, D.levels[l].nclusters);
+            fprintf(stderr, "L%lld tasks %d/%d+%d/%d+%d/%d+%d blocks %lld rows %lld mfma_stages %lld max %lld vec_blocks %lld vec_entries %lld clusters %d items %d (max %d K-steps)\n",
+                    (long long)l, D.levels[l].ntasks[0], D.levels[l].ntasks[1], D.levels[l].ntasks[2], D.levels[l].ntasks[3], D.levels[l].ntasks[4],
+                    D.levels[l].ntasks[5], D.levels[l].ntasks[6], (long long)nb, (long long)rows, (long long)stages, (long long)maxst, (long long)vblk,
+                    (long long)vec, D.levels[l].nclusters, D.levels[l].nitems, D.levels[l].item_ksteps_max);
         }
     }
     D.task_ptr.upload(P.task_ptr);
     D.hdr.upload(P.hdr);
     D.prologue.upload(P.prologue);
+    D.items.upload(P.items);
+    D.item_masks.upload(P.item_masks);
+    D.nitems = (i64)P.items.size();
+    D.item_entries = P.item_padded_entries;
     D.single_block_tasks = D.ntasks == D.nblocks;
     // the kernels fetch ids and coefficients a wavefront at a time (clamped lane offsets), never past these ends
     D.src_idx.upload(P.src_idx);
@@ -617,100 +629,47 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
     const i64 lean_wgs = env_or("RSP_LEAN_WGS", kLeanLaunchWorkgroups);
     const i64 lean_wgs_single = env_or("RSP_LEAN_WGS_SINGLE", kLeanLaunchWorkgroupsSingle);  // one right-hand side
     const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);
+    const i64 item_waves = env_or("RSP_ITEM_WAVES", kItemLaunchWaves);
+    const i64 item_ks = env_or("RSP_ITEM_KS", 0);  // 1, 2, 4: forced K-split of the item kernel (0: by the level's size)
+    const dev::ItemArrays IA{P.items.get(), P.src_idx.get(), P.coef.get(), P.item_masks.get()};
+    // A level's wide items run as items (64 x 64 register tiles) when the block is made of whole, aligned 64-column chunks and
+    // the level has enough of them to fill the chip; otherwise as their twin 16-row blocks
+    auto items_mode = [&](const BlockedProgram::Level &lv) {
+        return lv.nitems > 0 && fast && nrhs % 64 == 0 && item_waves > 0 && (i64)lv.nitems * nchunks >= item_waves;
+    };
     // workgroups of the whole sweep (a proxy for its work), to find the point where the heavy part is over
     i64 total = 0, done = 0;
+    auto level_work = [&](const BlockedProgram::Level &lv) {
+        const bool it = items_mode(lv);
+        return (i64)lv.nclusters * nchunks + ((i64)(lv.ntasks[0] + lv.ntasks[1] + (it ? 0 : lv.ntasks[2])) * nchunks + 7) / 8 +
+               ((i64)(lv.ntasks[3] + (it ? 0 : lv.ntasks[4])) * nchunks + 1) / 2 + (i64)(lv.ntasks[5] + (it ? 0 : lv.ntasks[6])) * nchunks +
+               (it ? (i64)lv.nitems * nchunks : 0);
+    };
     if (after_heavy)
-        for (const auto &lv : P.levels)
-            total += (i64)lv.nclusters * nchunks + ((i64)(lv.ntasks[0] + lv.ntasks[1]) * nchunks + 7) / 8 + ((i64)lv.ntasks[2] * nchunks + 1) / 2 +
-                     (i64)lv.ntasks[3] * nchunks;
-    // what the block kernel of one level runs, and with how many workgroups, for `chunks` column chunks per block
+        for (const auto &lv : P.levels) total += level_work(lv);
+    // what the block kernel of one level runs, and with how many workgroups, for `chunks` column chunks per block.  twins:
+    // the twin blocks of the level's wide items are included (classes 1+2, 3+4, 5+6 are contiguous in task and block order)
     auto small_alone_of = [&](const BlockedProgram::Level &lv) { return lv.ntasks[0] > 0 && (i64)lv.ntasks[0] * nchunks >= small_waves; };
-    auto describe = [&](const BlockedProgram::Level &lv, bool small_alone, int chunks, dev::LevelDesc &L) {
-        const int n01 = lv.ntasks[1] + (small_alone ? 0 : lv.ntasks[0]);  // classes 0 and 1 are consecutive tasks
+    auto describe = [&](const BlockedProgram::Level &lv, bool small_alone, bool twins, int chunks, dev::LevelDesc &L) {
+        const int n01 = lv.ntasks[1] + (twins ? lv.ntasks[2] : 0) + (small_alone ? 0 : lv.ntasks[0]);  // classes 0, 1 (and 2) are consecutive tasks
         L.task_begin = small_alone ? lv.task_begin[1] : lv.task_begin[0];
-        L.block_begin[0] = lv.block_begin[2];
-        L.block_begin[1] = lv.block_begin[3];
+        L.block_begin[0] = lv.block_begin[3];
+        L.block_begin[1] = lv.block_begin[5];
         L.blk0 = small_alone ? lv.block_begin[1] : lv.block_begin[0];
         L.rec0 = small_alone ? lv.rec_begin[1] : lv.rec_begin[0];
-        L.rec_begin[0] = lv.rec_begin[2];
-        L.rec_begin[1] = lv.rec_begin[3];
+        L.rec_begin[0] = lv.rec_begin[3];
+        L.rec_begin[1] = lv.rec_begin[5];
         L.single = P.single_block_tasks ? 1 : 0;
         L.ntasks = n01;
-        L.nblk[0] = lv.ntasks[2];
-        L.nblk[1] = lv.ntasks[3];
+        L.nblk[0] = lv.ntasks[3] + (twins ? lv.ntasks[4] : 0);
+        L.nblk[1] = lv.ntasks[5] + (twins ? lv.ntasks[6] : 0);
         L.wg0 = (int)(((i64)n01 * chunks + 7) / 8);
-        L.wg1 = (int)(((i64)lv.ntasks[2] * chunks + 1) / 2);
-        L.wg2 = (int)((i64)lv.ntasks[3] * chunks);
+        L.wg1 = (int)(((i64)L.nblk[0] * chunks + 1) / 2);
+        L.wg2 = (int)((i64)L.nblk[1] * chunks);
         return (unsigned)(((i64)L.wg0 + L.wg1 + L.wg2 + 7) / 8 * 8);  // whole rounds over the 8 XCDs
     };
     const bool narrow_block = nrhs <= 16;
     const i64 lean_threshold = nrhs == 1 ? lean_wgs_single : lean_wgs;
-
-    // ---- narrow blocks: runs of consecutive block-kernel-only levels as one launch each -------------------------------
-    // OFF by default: measured at C2 with one right-hand side, a level inside a merged launch costs ~13 us (agent-scope
-    // release + acquire, i.e. an L2 write-back and invalidate per workgroup, plus the flag's trip through memory) against
-    // ~9 us for a launch of its own: 2.87 ms per cholsol solve phase instead of 2.39.  RSP_MERGED=1 turns
-    // it on; the parity tests run both.
-    bool merged = narrow_block && env_or("RSP_MERGED", 0) != 0;
-    if (merged) {
-        const i64 key = lean_threshold * 1000003 + small_waves;
-        if (!(merged_.built && merged_.key == key)) {
-            if (scratch_override) {
-                merged = false;  // the allocation-free entry point builds nothing
-            } else {
-                MergedTables &T = merged_;
-                T.runs.clear();
-                T.run_at.assign(P.levels.size(), -1);
-                std::vector<dev::LevelDesc> descs, cur;
-                std::vector<int> wg_begin, cur_wgs;
-                int cur_first = 0, flag_words = 0;
-                auto flush = [&] {
-                    if ((i64)cur.size() >= kMergedMinLevels) {
-                        MergedTables::Run R{cur_first, (int)cur.size(), (int)descs.size(), (int)wg_begin.size(), 0, flag_words};
-                        wg_begin.push_back(0);
-                        for (size_t k = 0; k < cur.size(); ++k) {
-                            descs.push_back(cur[k]);
-                            R.total_wgs += cur_wgs[k];
-                            wg_begin.push_back(R.total_wgs);
-                        }
-                        flag_words += R.total_wgs;
-                        T.run_at[cur_first] = (int)T.runs.size();
-                        T.runs.push_back(R);
-                    }
-                    cur.clear();
-                    cur_wgs.clear();
-                };
-                for (size_t li = 0; li < P.levels.size(); ++li) {
-                    const auto &lv = P.levels[li];
-                    const bool small_alone = small_alone_of(lv);
-                    dev::LevelDesc L;
-                    const unsigned padded = describe(lv, small_alone, 1, L);
-                    const int wgs = L.wg0 + L.wg1 + L.wg2;  // merged launches do not pad levels to whole XCD rounds
-                    // levels of few workgroups only: the deep-ring variant, and a wait that one wavefront can poll
-                    const bool joins = !lv.nclusters && !small_alone && wgs > 0 && padded < (unsigned)lean_threshold &&
-                                       wgs <= dev::kMergedMaxLevelWorkgroups;
-                    if (!joins) {
-                        flush();
-                        continue;
-                    }
-                    if (cur.empty()) cur_first = (int)li;
-                    cur.push_back(L);
-                    cur_wgs.push_back(wgs);
-                }
-                flush();
-                if (!descs.empty()) {
-                    T.levels.resize(descs.size() * sizeof(dev::LevelDesc));
-                    RSP_HIP(hipMemcpy(T.levels.get(), descs.data(), descs.size() * sizeof(dev::LevelDesc), hipMemcpyHostToDevice));
-                    T.wg_begin.upload(wg_begin.data(), wg_begin.size());
-                    T.counters.resize((size_t)flag_words + 1);
-                    RSP_HIP(hipMemset(T.counters.get(), 0, T.counters.size() * sizeof(unsigned)));
-                    T.epoch = 0;
-                }
-                T.key = key;
-                T.built = true;
-            }
-        }
-    }
 
     bool recorded = false;
     for (size_t li = 0; li < P.levels.size(); ++li) {
@@ -719,21 +678,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             RSP_HIP(hipEventRecord(after_heavy, stream));
             recorded = true;
         }
-        if (merged && merged_.run_at[li] >= 0) {
-            const MergedTables::Run &R = merged_.runs[merged_.run_at[li]];
-            if (++merged_.epoch == 0) {  // wrapped after 2^32 launches: old flag words could match again, start over
-                RSP_HIP(hipMemsetAsync(merged_.counters.get(), 0, (merged_.counters.size() - 1) * sizeof(unsigned), stream));
-                merged_.epoch = 1;
-            }
-            const dev::MergedRun M{reinterpret_cast<const dev::LevelDesc *>(merged_.levels.get()) + R.desc_off, merged_.wg_begin.get() + R.wg_off,
-                                   merged_.counters.get() + R.flag_off, merged_.counters.get() + merged_.counters.size() - 1, R.nlevels, merged_.epoch};
-            auto kernel = fast ? dev::solve_levels_merged<true, true, 1> : dev::solve_levels_merged<false, true, 1>;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)R.total_wgs), dim3(512), 7 * 8192, stream, A, M, X, ld, Sw, lds, (int)nrhs, 1);
-            done += R.total_wgs;
-            li += (size_t)R.nlevels - 1;
-            continue;
-        }
-        done += (i64)lv.nclusters * nchunks + ((i64)lv.ntasks[0] * nchunks + 7) / 8;
+        done += level_work(lv);
         if (lv.nclusters && P.dense) {  // dense tasks: one single-wavefront workgroup per (task, 16 * NT columns)
             const i64 dense_nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
             const int nt = dense_nt >= 4 ? 4 : dense_nt >= 2 ? 2 : 1;
@@ -761,8 +706,17 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             hipLaunchKernelGGL(dev::solve_level_small, dim3((unsigned)((((i64)lv.ntasks[0] * nchunks + 3) / 4 + 7) / 8 * 8)), dim3(256), 0,
                                stream, A, lv.task_begin[0], lv.ntasks[0], X, ld, Sw, lds, (int)nrhs, nchunks, lv.block_begin[0], lv.rec_begin[0],
                                P.single_block_tasks ? 1 : 0);
+        // the level's wide items, as items: whole K-steps per wavefront when there are enough (item, chunk) pairs to fill the
+        // chip, else shared by two or four wavefronts (levels of few, long items)
+        const bool as_items = items_mode(lv);
+        if (as_items) {
+            const i64 pairs = (i64)lv.nitems * nchunks;
+            int ksplit = pairs >= 2048 || lv.item_ksteps_max < 64 ? 1 : pairs >= 1024 || lv.item_ksteps_max < 128 ? 2 : 4;
+            if (item_ks == 1 || item_ks == 2 || item_ks == 4) ksplit = (int)item_ks;
+            dev::launch_items(ksplit, IA, lv.item_begin, lv.nitems, nchunks, X, ld, Sw, lds, stream);
+        }
         dev::LevelDesc L;
-        unsigned wgs = describe(lv, small_alone, nchunks, L);
+        unsigned wgs = describe(lv, small_alone, !as_items, nchunks, L);
         if (wgs) {
             // Few workgroups: a workgroup's own chain (round trips, then its matrix-core time) is the launch's duration --
             // the deep-ring variant, and 16 columns per wavefront instead of 64 so that four times as many compute units
@@ -773,7 +727,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             const bool nt1 = pipe && narrow && nrhs > 16;  // (blocks of at most 16 columns: see narrow_block)
             if (nt1) {
                 level_chunks = (int)((nrhs + 15) / 16);
-                wgs = describe(lv, small_alone, level_chunks, L);
+                wgs = describe(lv, small_alone, !as_items, level_chunks, L);
             }
             // Blocks of at most 16 columns (one right-hand side among them) always run 16-column wavefronts (one column
             // tile: a quarter of the registers), lean on heavy levels.  Wider UNALIGNED blocks (element-wise path) have no
@@ -784,10 +738,9 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
                                        : (nt1 ? dev::solve_level<false, true, 1> : dev::solve_level<false, true, 4>);
             if (narrow_block && !nt1) {
                 level_chunks = 1;
-                wgs = describe(lv, small_alone, level_chunks, L);
+                wgs = describe(lv, small_alone, !as_items, level_chunks, L);
             }
             hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 7 * 8192, stream, A, L, X, ld, Sw, lds, (int)nrhs, level_chunks);
-            done += wgs;
 #ifdef RSP_TRI_CLOCKS
             if (getenv("RSP_TRI_CLOCKS") && L.wg2 > 0) {
                 RSP_HIP(hipStreamSynchronize(stream));
@@ -948,14 +901,6 @@ void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream
     RSP_HIP(hipGetLastError());
 }
 
-bool TriSolver::merged_failed()
-{
-    if (!merged_.built || merged_.counters.size() == 0) return false;
-    unsigned flag = 0;
-    RSP_HIP(hipMemcpy(&flag, merged_.counters.get() + merged_.counters.size() - 1, sizeof(flag), hipMemcpyDeviceToHost));
-    return flag != 0;
-}
-
 void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
 {
     if (nrhs <= 0 || n_ == 0) return;
@@ -963,7 +908,6 @@ void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
     copy_block_to_device(d.get(), X, n_, ldx, nrhs);
     solve_device(d.get(), 0, n_, nrhs, nullptr);
     RSP_HIP(hipDeviceSynchronize());
-    if (merged_failed()) throw DeviceError("a merged-level launch gave up waiting for its previous level");
     copy_block_to_host(X, d.get(), n_, ldx, nrhs);
 }
 

@@ -148,6 +148,11 @@ class Builder {
         if (const char *e = std::getenv("RSP_DENSE_FILL")) dense_fill_ = std::atof(e);
         emit_threads_ = host_threads();  // RSP_EMIT_THREADS=0: the sequential path (the programme does not depend on it)
         tune("RSP_EMIT_THREADS", emit_threads_);
+        tune("RSP_ITEM_ROWS", item_rows_);
+        item_rows_ = item_rows_ >= 64 ? 64 : item_rows_ >= 48 ? 48 : item_rows_ >= 32 ? 32 : 16;
+        tune("RSP_SORT_ROWS", sort_rows_);
+        tune("RSP_ITEM_MIN_SOURCES", item_min_sources_);
+        if (const char *e = std::getenv("RSP_ITEM_MIN_FILL")) item_min_fill_ = std::atof(e);
     }
 
     BlockProgram run()
@@ -769,7 +774,7 @@ class Builder {
     // sources order[0, distinct) and the triples src[0, nsrc) whose ranks start at rank_base
     template <class IdOf>
     void append_block(int rows, const int32_t *dest, const int32_t *init, const int32_t *order, i64 distinct, const Triple *src, size_t nsrc,
-                      int32_t rank_base, IdOf id_of, i64 level)
+                      int32_t rank_base, IdOf id_of, i64 level, bool twin = false)
     {
         const int rc = distinct >= split_sources_ ? 16 : class_of(rows);
         const i64 b = (i64)P_.hdr.size();
@@ -797,6 +802,198 @@ class Builder {
         task_first_blk_.push_back(b);
         task_level_.push_back((int32_t)level);
         task_nblk_.push_back(1);
+        task_tile_.resize(task_level_.size(), 0);
+        task_tile_.back() = twin ? 1 : 0;
+    }
+
+
+    // one row tile of an item: a ranked 16-row group, or one PART of it (sources order[0, cnt), triples whose ranks start at rank_base)
+    struct TileView {
+        bool present = false;  // (a tile with fewer parts than its neighbours is absent from the later part items)
+        int rows = 0;
+        const int32_t *dest = nullptr, *init = nullptr, *order = nullptr;
+        i64 cnt = 0;
+        const Triple *src = nullptr;
+        size_t nsrc = 0;
+        int32_t rank_base = 0;
+    };
+
+    // ONE WIDE ITEM (sparse.hpp) over up to four tiles of one chain phase, all at `level`: the union of their source lists,
+    // a 4-bit mask per source (which tiles use it), sources ordered by mask (then by position) so that the K-steps of a
+    // tile's zero blocks bunch together and are skipped as whole K-steps.  The same arithmetic is also emitted as the
+    // tiles' own 16-row blocks (the item's TWINS, task classes 2 / 4 / 6); a level runs one view or the other
+    // (dev::solve_items or the block kernel), decided at launch time.
+    template <class IdOf>
+    void append_item(const TileView *g, int mt, IdOf id_of, i64 level)
+    {
+        // union of the sorted lists, with masks
+        item_union_.clear();
+        item_mask_.clear();
+        i64 at[4] = {0, 0, 0, 0};
+        while (true) {
+            int32_t next = INT32_MAX;
+            for (int q = 0; q < mt; ++q)
+                if (g[q].present && at[q] < g[q].cnt) next = std::min(next, g[q].order[at[q]]);
+            if (next == INT32_MAX) break;
+            uint8_t m = 0;
+            for (int q = 0; q < mt; ++q)
+                if (g[q].present && at[q] < g[q].cnt && g[q].order[at[q]] == next) {
+                    m |= (uint8_t)(1 << q);
+                    ++at[q];
+                }
+            item_union_.push_back(next);
+            item_mask_.push_back(m);
+        }
+        const i64 ns = (i64)item_union_.size();
+        // order by mask: the bucket of mask 15 first, then the others by descending value; positions ascending inside a bucket
+        i64 bucket[17] = {0};
+        for (uint8_t m : item_mask_) bucket[16 - m]++;  // (mask m -> bucket 15 - m, shifted by one for the prefix sum)
+        for (int k = 1; k <= 16; ++k) bucket[k] += bucket[k - 1];
+        item_perm_.resize((size_t)ns);
+        for (i64 u = 0; u < ns; ++u) item_perm_[(size_t)u] = (int32_t)bucket[15 - item_mask_[(size_t)u]]++;
+        const i64 ns4 = (ns + 3) / 4 * 4, ks = ns4 / 4;
+        const i64 nwin = (ks + 15) / 16;
+        // which row tiles have entries in each K-step (the OR of its four sources' masks); only those 16 x 4 coefficient blocks
+        // are stored, K-step by K-step, tiles ascending inside a K-step
+        item_kmask_.assign((size_t)ks, 0);
+        for (i64 u = 0; u < ns; ++u) item_kmask_[(size_t)(item_perm_[(size_t)u] / 4)] |= item_mask_[(size_t)u];
+        item_kfirst_.resize((size_t)ks + 1);
+        item_kfirst_[0] = 0;
+        for (i64 k = 0; k < ks; ++k) item_kfirst_[(size_t)k + 1] = item_kfirst_[(size_t)k] + __builtin_popcount(item_kmask_[(size_t)k]);
+        const i64 nblocks = item_kfirst_[(size_t)ks];
+        const size_t cbase = P_.coef.size();
+        grow_coef(cbase + (size_t)nblocks * 64);
+        for (int q = 0; q < mt; ++q) {
+            if (!g[q].present) continue;
+            // rank inside the tile's list -> rank inside the union (both lists ascending)
+            item_map_.resize((size_t)g[q].cnt);
+            size_t u = 0;
+            for (i64 e = 0; e < g[q].cnt; ++e) {
+                while (item_union_[u] != g[q].order[e]) ++u;
+                item_map_[(size_t)e] = item_perm_[u];
+            }
+            const unsigned below = (1u << q) - 1u;
+            for (size_t k = 0; k < g[q].nsrc; ++k) {
+                const Triple &x = g[q].src[k];
+                const i64 e = item_map_[(size_t)(x.pos - g[q].rank_base)];
+                const i64 blk = item_kfirst_[(size_t)(e / 4)] + __builtin_popcount(item_kmask_[(size_t)(e / 4)] & below);
+                const size_t c = cbase + (size_t)blk * 64 + (size_t)(e % 4) * 16 + (size_t)x.slot;
+                P_.coef[c] += x.val;  // duplicates add up
+                set_code(c, x.code);
+            }
+        }
+        WideItem it{mt, (int32_t)ks, (i64)cbase, (i64)P_.src_idx.size(), (i64)P_.item_masks.size()};
+        for (int q = 0; q < mt; ++q)
+            for (int r = 0; r < 16; ++r) P_.src_idx.push_back(g[q].present && r < g[q].rows ? g[q].dest[r] : kNone);
+        for (int q = 0; q < mt; ++q)
+            for (int r = 0; r < 16; ++r) P_.src_idx.push_back(g[q].present && r < g[q].rows ? g[q].init[r] : kNone);
+        const size_t in0 = P_.src_idx.size();
+        P_.src_idx.resize(in0 + (size_t)ns4, 0);
+        for (i64 u = 0; u < ns; ++u) P_.src_idx[in0 + (size_t)item_perm_[(size_t)u]] = id_of(item_union_[(size_t)u]);
+        for (i64 u = ns; u < ns4; ++u) P_.src_idx[in0 + (size_t)u] = P_.src_idx[in0 + (size_t)ns - 1];  // padding: zero coefficients
+        for (i64 w = 0; w < nwin; ++w) {  // per window of 16 K-steps: 4 mask bits per K-step (two words), then the blocks before the window
+            uint64_t m = 0;
+            for (i64 k = 16 * w; k < std::min(ks, 16 * w + 16); ++k) m |= (uint64_t)item_kmask_[(size_t)k] << (4 * (k - 16 * w));
+            P_.item_masks.push_back((uint32_t)(m & 0xffffffffu));
+            P_.item_masks.push_back((uint32_t)(m >> 32));
+            P_.item_masks.push_back((uint32_t)item_kfirst_[(size_t)(16 * w)]);
+            P_.item_masks.push_back(0);
+        }
+        P_.item_padded_entries += 64 * nblocks;
+        P_.items.push_back(it);
+        item_level_.push_back((int32_t)level);
+    }
+
+    // Up to four ranked 16-row groups of one chain phase, all gathered at `level`: their blocks (partial sums into scratch
+    // rows plus a combine block at level + 1 for source lists longer than max_block_sources_) and, over the same rows and
+    // the same partial sums, the wide items -- one per part -- whose twins those blocks are.  Returns the level at which
+    // every destination row is complete.
+    template <class IdOf>
+    i64 emit_tiles(const RankedGroup *const *g, int mt, IdOf id_of, i64 level)
+    {
+        // An item pays where its wavefronts have long runs of K-steps ahead of them, most of them with work for every row
+        // tile (measured: the chains of the 2-D Laplacian 1024^2 average 30 K-steps per item, and lsolve's row tiles share
+        // half of their union list -- the twin blocks are faster there; 3-D 80^3: items 12 % faster overall).
+        bool item = false;
+        if (item_rows_ >= 32 && mt >= 2) {
+            i64 longest = 0, parts = 1, own = 0, dense = 0;
+            for (int q = 0; q < mt; ++q) {
+                longest = std::max<i64>(longest, std::min<i64>((i64)g[q]->order.size(), g[q]->parts > 1 ? g[q]->per : INT32_MAX));
+                parts = std::max(parts, g[q]->parts);
+                own += (i64)g[q]->order.size();
+            }
+            if (longest >= item_min_sources_) {
+                for (i64 p = 0; p < parts; ++p) {  // size of the union list of every part
+                    const int32_t *at[4], *end[4];
+                    for (int q = 0; q < mt; ++q) {
+                        const RankedGroup &G = *g[q];
+                        const i64 ns = (i64)G.order.size();
+                        const i64 first = G.parts == 1 ? 0 : p * G.per, cnt = p >= G.parts ? 0 : G.parts == 1 ? ns : std::min(G.per, ns - first);
+                        at[q] = G.order.data() + std::min(first, ns);
+                        end[q] = at[q] + cnt;
+                    }
+                    while (true) {
+                        int32_t next = INT32_MAX;
+                        for (int q = 0; q < mt; ++q)
+                            if (at[q] < end[q]) next = std::min(next, *at[q]);
+                        if (next == INT32_MAX) break;
+                        for (int q = 0; q < mt; ++q)
+                            if (at[q] < end[q] && *at[q] == next) ++at[q];
+                        dense += mt;
+                    }
+                }
+                item = (double)own >= item_min_fill_ * (double)dense;
+            }
+        }
+        i64 max_parts = 1, done = level;
+        std::vector<int32_t> pdest[4];
+        int32_t none[16];
+        std::fill(none, none + 16, kNone);
+        for (int q = 0; q < mt; ++q) {
+            const RankedGroup &G = *g[q];
+            const i64 ns = (i64)G.order.size();
+            max_parts = std::max(max_parts, G.parts);
+            if (G.parts == 1) {
+                append_block(G.rows, G.dest, G.init, G.order.data(), ns, G.src.data(), G.src.size(), 0, id_of, level, item);
+                continue;
+            }
+            const int rows = G.rows;
+            pdest[q].resize((size_t)G.parts * rows);
+            for (i64 p = 0; p < G.parts; ++p) {
+                for (int r = 0; r < rows; ++r) pdest[q][(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
+                const i64 first = p * G.per, cnt = std::min(G.per, ns - first);
+                append_block(rows, &pdest[q][(size_t)p * rows], p == 0 ? G.init : none, G.order.data() + first, cnt, G.src.data() + G.part_off[p],
+                             (size_t)(G.part_off[p + 1] - G.part_off[p]), (int32_t)first, id_of, level, item);
+            }
+            // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial); runs in both views
+            std::vector<Triple> comb;
+            for (i64 p = 1; p < G.parts; ++p)
+                for (int r = 0; r < rows; ++r) comb.push_back(Triple{(int32_t)((p - 1) * rows + r), r, -1.0});
+            const int32_t *p1 = pdest[q].data() + rows;
+            push_block(rows, G.dest, pdest[q].data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, nullptr, level + 1, true);
+            done = level + 1;
+        }
+        if (item)
+            for (i64 p = 0; p < max_parts; ++p) {
+                TileView v[4];
+                for (int q = 0; q < mt; ++q) {
+                    const RankedGroup &G = *g[q];
+                    if (p >= G.parts) continue;
+                    const i64 ns = (i64)G.order.size();
+                    const i64 first = G.parts == 1 ? 0 : p * G.per, cnt = G.parts == 1 ? ns : std::min(G.per, ns - first);
+                    v[q].present = true;
+                    v[q].rows = G.rows;
+                    v[q].dest = G.parts == 1 ? G.dest : &pdest[q][(size_t)p * G.rows];
+                    v[q].init = (G.parts == 1 || p == 0) ? G.init : none;
+                    v[q].order = G.order.data() + first;
+                    v[q].cnt = cnt;
+                    v[q].src = G.parts == 1 ? G.src.data() : G.src.data() + G.part_off[p];
+                    v[q].nsrc = G.parts == 1 ? G.src.size() : (size_t)(G.part_off[p + 1] - G.part_off[p]);
+                    v[q].rank_base = (int32_t)first;
+                }
+                append_item(v, mt, id_of, level);
+            }
+        return done;
     }
 
     // distinct sources and ranks of a group's triples (pos = processing position on entry, rank on return), cut into
@@ -826,36 +1023,6 @@ class Builder {
             for (const Triple &x : g.src) sorted[(size_t)fill[(size_t)(x.pos / g.per)]++] = x;
             g.src.swap(sorted);
         }
-    }
-
-    // emit_gather for a ranked group (the same blocks, scratch rows and levels)
-    template <class IdOf>
-    i64 emit_gather_ranked(const RankedGroup &g, IdOf id_of, i64 level)
-    {
-        const i64 ns = (i64)g.order.size();
-        if (g.parts == 1) {
-            append_block(g.rows, g.dest, g.init, g.order.data(), ns, g.src.data(), g.src.size(), 0, id_of, level);
-            return level;
-        }
-        const int rows = g.rows;
-        std::vector<int32_t> pdest((size_t)g.parts * rows);
-        for (i64 p = 0; p < g.parts; ++p) {
-            int32_t none[16];
-            for (int r = 0; r < rows; ++r) {
-                pdest[(size_t)p * rows + r] = ~(int32_t)(P_.scratch_rows++);
-                none[r] = kNone;
-            }
-            const i64 first = p * g.per, cnt = std::min(g.per, ns - first);
-            append_block(rows, &pdest[(size_t)p * rows], p == 0 ? g.init : none, g.order.data() + first, cnt, g.src.data() + g.part_off[p],
-                         (size_t)(g.part_off[p + 1] - g.part_off[p]), (int32_t)first, id_of, level);
-        }
-        // combine: dest = partial_0 + sum_{p>=1} partial_p   (acc -= (-1) * partial)
-        std::vector<Triple> comb;
-        for (i64 p = 1; p < g.parts; ++p)
-            for (int r = 0; r < rows; ++r) comb.push_back(Triple{(int32_t)((p - 1) * rows + r), r, -1.0});
-        const int32_t *p1 = pdest.data() + rows;
-        push_block(rows, g.dest, pdest.data(), comb, [&](int32_t o) { return p1[o]; }, nullptr, nullptr, level + 1, true);
-        return level + 1;
     }
 
     // ---- gather into dest with the source list cut into partial sums of at most kMaxBlockSources sources ----------
@@ -928,6 +1095,11 @@ class Builder {
     }
 
     // ---- long dense chains: Y = X_J - L[J,ext] X_ext ; X_J = M^-1 Y ------------------------------------------
+    // Both phases are emitted as 16-row blocks and, over the same rows, as WIDE ITEMS of up to item_rows_ unknowns (the
+    // blocks are then the item's twins: append_item).  The rows of phase A are independent of each other, so they are
+    // free to be GROUPED in any order: rows with similar source lists go into the same group (similar_row_order), which
+    // keeps the union list of a group -- every row of a group pays for every source of the union -- close to the rows'
+    // own lists (lsolve / usolve: the rows of a supernode do not share their sources).
     void emit_big_chain(i64 t0, i64 t1)
     {
         close_task();
@@ -945,12 +1117,16 @@ class Builder {
         ck.lap(4);
         const i64 y0 = P_.scratch_rows;
         P_.scratch_rows += w;
+        const i64 tiles_per_item = std::max<i64>(1, item_rows_ / 16);
         // phase A per group of 16 unknowns: all groups independent
+        std::vector<i64> rows_in_order((size_t)w);
+        for (i64 k = 0; k < w; ++k) rows_in_order[(size_t)k] = t0 + k;
+        if (sort_rows_ && w > 16) similar_row_order(t0, t1, rows_in_order);
         i64 ready = 0;
-        if (emit_threads_ > 0) {
+        {
             // the triples of a group, its distinct sources and their ranks are a pure function of the gather form (and of
             // avail_, which this chain does not change before its end): batches of groups are prepared on the host
-            // threads, then appended in order -- the programme is the same as from the sequential path below
+            // threads, then appended in order -- the programme does not depend on the number of threads
             const i64 ngroups = (w + 15) / 16;
             const i64 T = std::max<i64>(1, std::min<i64>(emit_threads_, ngroups));
             if ((i64)tstamp_.size() < T) {
@@ -958,7 +1134,7 @@ class Builder {
                 trank_.resize((size_t)T);
                 tstamp_id_.resize((size_t)T, 0);
             }
-            const i64 batch = 4 * T;
+            const i64 batch = 4 * T;  // (a multiple of 4: the groups of an item are prepared together)
             std::vector<RankedGroup> work((size_t)std::min(batch, ngroups));
             for (i64 g0 = 0; g0 < ngroups; g0 += batch) {
                 const i64 g1 = std::min(ngroups, g0 + batch);
@@ -969,13 +1145,14 @@ class Builder {
                     }
                     for (i64 g = g0 + k; g < g1; g += T) {
                         RankedGroup &G = work[(size_t)(g - g0)];
-                        const i64 a = t0 + 16 * g, b = std::min(a + 16, t1);
+                        const i64 a = 16 * g, b = std::min(a + 16, w);
                         G.rows = (int)(b - a);
                         G.src.clear();
                         G.need = 0;
-                        for (i64 t = a; t < b; ++t) {
+                        for (i64 q = a; q < b; ++q) {
+                            const i64 t = rows_in_order[(size_t)q];
                             const i64 r = row_at(t);
-                            const int slot = (int)(t - a);
+                            const int slot = (int)(q - a);
                             G.dest[slot] = ~(int32_t)(y0 + (t - t0));
                             G.init[slot] = (int32_t)r;
                             for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
@@ -998,56 +1175,36 @@ class Builder {
                     for (std::thread &th : pool) th.join();
                 }
                 ck.lap(5);
-                for (i64 g = g0; g < g1; ++g) {
-                    const i64 done = emit_gather_ranked(work[(size_t)(g - g0)], [&](int32_t pos) { return (int32_t)row_at(pos); }, work[(size_t)(g - g0)].need);
-                    ready = std::max(ready, done);
+                auto id_of = [&](int32_t pos) { return (int32_t)row_at(pos); };
+                for (i64 g = g0; g < g1; g += tiles_per_item) {
+                    const int mt = (int)std::min<i64>(tiles_per_item, g1 - g);
+                    const RankedGroup *grp[4];
+                    i64 level = 0;
+                    for (int q = 0; q < mt; ++q) {
+                        grp[q] = &work[(size_t)(g + q - g0)];
+                        level = std::max(level, grp[q]->need);
+                    }
+                    ready = std::max(ready, emit_tiles(grp, mt, id_of, level));  // (the tiles of an item share its level)
                 }
                 ck.lap(6);
             }
-        } else
-        for (i64 a = t0; a < t1; a += 16) {
-            const i64 b = std::min(a + 16, t1);
-            const int rows = (int)(b - a);
-            int32_t dest[16], init[16];
-            src_.clear();
-            i64 need = 0;
-            for (i64 t = a; t < b; ++t) {
-                const i64 r = row_at(t);
-                const int slot = (int)(t - a);
-                dest[slot] = ~(int32_t)(y0 + (t - t0));
-                init[slot] = (int32_t)r;
-                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
-                    const i64 s = G_.idx[p];
-                    const i64 ps = pos_of(s);
-                    if (ps >= t0) continue;
-                    src_.push_back(Triple{(int32_t)ps, slot, G_.val[p], (int32_t)p});
-                    need = std::max<i64>(need, avail_[s] + 1);
-                }
-            }
-            ck.lap(5);
-            const i64 done = emit_gather(rows, dest, init, src_, [&](int32_t pos) { return (int32_t)row_at(pos); }, need);
-            ck.lap(6);
-            ready = std::max(ready, done);
         }
-        // phase B: X_J = Minv * Y, all groups independent
+        // phase B: X_J = Minv * Y, all groups independent.  The sources of a group are the scratch rows 0 .. b - t0 - 1, every
+        // one of them used: a source's rank is its number, and triples generated source by source are already grouped by part
         i64 final_level = ready + 1;
-        for (i64 a = t0; a < t1; a += 16) {
-            const i64 b = std::min(a + 16, t1);
-            const int rows = (int)(b - a);
-            int32_t dest[16], init[16];
-            src_.clear();
-            for (i64 t = a; t < b; ++t) {
-                dest[t - a] = (int32_t)row_at(t);
-                init[t - a] = kNone;
-            }
-            i64 done;
-            if (emit_threads_ > 0) {
-                // the sources are the scratch rows 0 .. b - t0 - 1, every one of them used: a source's rank is its number, and
-                // triples generated source by source are already grouped by part
-                RankedGroup &G = chain_group_;
-                G.rows = rows;
-                std::copy(dest, dest + 16, G.dest);
-                std::copy(init, init + 16, G.init);
+        auto id_of_y = [&](int32_t o) { return ~(int32_t)(y0 + o); };
+        for (i64 a0 = t0; a0 < t1; a0 += 16 * tiles_per_item) {
+            const int mt = (int)std::min<i64>(tiles_per_item, (t1 - a0 + 15) / 16);
+            const RankedGroup *grp[4];
+            for (int q = 0; q < mt; ++q) {
+                const i64 a = a0 + 16 * q, b = std::min(a + 16, t1);
+                RankedGroup &G = chain_groups_[q];
+                grp[q] = &G;
+                G.rows = (int)(b - a);
+                for (i64 t = a; t < b; ++t) {
+                    G.dest[t - a] = (int32_t)row_at(t);
+                    G.init[t - a] = kNone;
+                }
                 const i64 ns = b - t0;
                 G.order.resize((size_t)ns);
                 for (i64 u = 0; u < ns; ++u) G.order[(size_t)u] = (int32_t)u;
@@ -1061,15 +1218,8 @@ class Builder {
                     G.part_off[(size_t)(u / G.per) + 1] = (i64)G.src.size();
                 }
                 for (i64 p = 0; p < G.parts; ++p) G.part_off[p + 1] = std::max(G.part_off[p + 1], G.part_off[p]);
-                done = emit_gather_ranked(G, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
-            } else {
-                // generated in (source, slot) order: the sorts downstream see sorted input and skip
-                for (i64 u = 0; u < b - t0; ++u)
-                    for (i64 t = std::max(a, t0 + u); t < b; ++t)
-                        src_.push_back(Triple{(int32_t)u, (int)(t - a), -Minv[(size_t)(t - t0) * w + u], pool_code(pool_off + (t - t0) * w + u)});
-                done = emit_gather(rows, dest, init, src_, [&](int32_t o) { return ~(int32_t)(y0 + o); }, ready + 1);
             }
-            final_level = std::max(final_level, done);
+            final_level = std::max(final_level, emit_tiles(grp, mt, id_of_y, ready + 1));
         }
         for (i64 t = t0; t < t1; ++t) {
             avail_[row_at(t)] = (int32_t)final_level;
@@ -1078,6 +1228,120 @@ class Builder {
         close_task();
         ck.lap(5);
         for (int k = 3; k <= 6; ++k) clock_.acc[k] += ck.acc[k];
+    }
+
+    // Order of the rows of a chain (positions [t0, t1)) for phase A, such that the rows of one item have similar source
+    // lists.  Greedy: an item starts from the unassigned row with the longest list and takes, one at a time, the
+    // unassigned row whose list adds the fewest new sources to the item's union (ties: the longer list, then the lower
+    // position).  The lists of a supernode's rows are unions of whole runs of consecutive positions (descendant
+    // supernodes), so they are compared as lists of SEGMENTS -- maximal runs of consecutive source positions that belong
+    // to the same set of rows -- weighted by their length: tens of segments per row instead of hundreds of sources.
+    // Pure function of the gather form.
+    void similar_row_order(i64 t0, i64 t1, std::vector<i64> &out)
+    {
+        const i64 w = t1 - t0, R = 16;  // (the rows of a block; an item takes four consecutive blocks)
+        if (rank_.empty()) rank_.assign(n_, 0);
+        // distinct sources of the chain, ascending
+        ++stamp_id_;
+        order_.clear();
+        bool all_same = true;
+        i64 first_len = -1;
+        for (i64 k = 0; k < w; ++k) {
+            const i64 r = row_at(t0 + k);
+            i64 len = 0;
+            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                const i64 ps = pos_of(G_.idx[p]);
+                if (ps >= t0) continue;
+                ++len;
+                if (stamp_[ps] != stamp_id_) {
+                    stamp_[ps] = stamp_id_;
+                    order_.push_back((int32_t)ps);
+                    if (k > 0) all_same = false;  // a source the first row does not have
+                }
+            }
+            if (k == 0) first_len = len;
+            else if (len != first_len) all_same = false;
+        }
+        if (all_same || order_.empty()) return;  // (ltsolve / utsolve on a supernode: every row has the same list)
+        std::sort(order_.begin(), order_.end());
+        const i64 nu = (i64)order_.size();
+        for (i64 k = 0; k < nu; ++k) rank_[order_[(size_t)k]] = (int32_t)k;
+        // membership hash per source, then segments
+        std::vector<uint64_t> hash((size_t)nu, 0);
+        auto mix = [](uint64_t z) {
+            z += 0x9e3779b97f4a7c15ull;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            return z ^ (z >> 31);
+        };
+        for (i64 k = 0; k < w; ++k) {
+            const i64 r = row_at(t0 + k);
+            const uint64_t hk = mix((uint64_t)k);
+            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                const i64 ps = pos_of(G_.idx[p]);
+                if (ps < t0) hash[(size_t)rank_[ps]] += hk;  // (a duplicate entry counts twice, in every comparison alike)
+            }
+        }
+        std::vector<int32_t> seg_of((size_t)nu);
+        std::vector<int32_t> seg_len;
+        for (i64 k = 0; k < nu; ++k) {
+            if (k == 0 || order_[(size_t)k] != order_[(size_t)k - 1] + 1 || hash[(size_t)k] != hash[(size_t)k - 1]) seg_len.push_back(0);
+            seg_of[(size_t)k] = (int32_t)seg_len.size() - 1;
+            seg_len.back()++;
+        }
+        const i64 nseg = (i64)seg_len.size();
+        // per row: its segments (each once) and the length of its list
+        std::vector<i64> row_ptr((size_t)w + 1, 0), row_len((size_t)w, 0);
+        std::vector<int32_t> row_seg;
+        std::vector<i64> seg_stamp((size_t)nseg, -1);
+        for (i64 k = 0; k < w; ++k) {
+            const i64 r = row_at(t0 + k);
+            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
+                const i64 ps = pos_of(G_.idx[p]);
+                if (ps >= t0) continue;
+                const int32_t sg = seg_of[(size_t)rank_[ps]];
+                if (seg_stamp[(size_t)sg] != k) {
+                    seg_stamp[(size_t)sg] = k;
+                    row_seg.push_back(sg);
+                    row_len[(size_t)k] += seg_len[(size_t)sg];
+                }
+            }
+            row_ptr[(size_t)k + 1] = (i64)row_seg.size();
+        }
+        std::vector<char> used((size_t)w, 0), in_union((size_t)nseg, 0);
+        std::vector<int32_t> touched;
+        i64 at = 0;
+        while (at < w) {
+            i64 seed = -1;
+            for (i64 k = 0; k < w; ++k)
+                if (!used[(size_t)k] && (seed < 0 || row_len[(size_t)k] > row_len[(size_t)seed])) seed = k;
+            touched.clear();
+            auto take = [&](i64 k) {
+                used[(size_t)k] = 1;
+                out[(size_t)at++] = t0 + k;
+                for (i64 q = row_ptr[(size_t)k]; q < row_ptr[(size_t)k + 1]; ++q)
+                    if (!in_union[(size_t)row_seg[(size_t)q]]) {
+                        in_union[(size_t)row_seg[(size_t)q]] = 1;
+                        touched.push_back(row_seg[(size_t)q]);
+                    }
+            };
+            take(seed);
+            for (i64 m = 1; m < R && at < w; ++m) {
+                i64 best = -1, best_add = 0;
+                for (i64 k = 0; k < w; ++k) {
+                    if (used[(size_t)k]) continue;
+                    i64 add = 0;
+                    for (i64 q = row_ptr[(size_t)k]; q < row_ptr[(size_t)k + 1]; ++q)
+                        if (!in_union[(size_t)row_seg[(size_t)q]]) add += seg_len[(size_t)row_seg[(size_t)q]];
+                    if (best < 0 || add < best_add || (add == best_add && row_len[(size_t)k] > row_len[(size_t)best])) {
+                        best = k;
+                        best_add = add;
+                    }
+                }
+                take(best);
+            }
+            for (int32_t sg : touched) in_union[(size_t)sg] = 0;
+        }
     }
 
     // ---- order tasks and clusters by level ------------------------------------------------------------------
@@ -1103,13 +1367,17 @@ class Builder {
             for (i64 c = 0; c < nclusters; ++c)
                 if (!read[emit_order_[c]]) cluster_level_[c] = (int32_t)(nlev - 1);
         }
-        // inside a level, tasks are grouped by class: 0 = only small (vector-path) blocks, 1 = one wavefront per
-        // (task, 64 columns) with at least one matrix-core block, 2 / 3 = one matrix-core block whose sources are
-        // split over 4 / 8 wavefronts
+        // inside a level, tasks are grouped by class (BlockProgram::kClasses): 0 = only small (vector-path) blocks, 1 = one
+        // wavefront per (task, 64 columns) with at least one matrix-core block, 3 / 5 = one matrix-core block whose sources
+        // are split over 4 / 8 wavefronts; 2, 4, 6 = the same for the row tiles of wide items
         constexpr int NC = BlockProgram::kClasses;
+        task_tile_.resize((size_t)ntasks, 0);
+        for (int32_t l : item_level_) nlev = std::max<i64>(nlev, l + 1);
         auto task_class = [&](i64 t) {
             const BlockHeader &h = P_.hdr[task_first_blk_[t]];
-            if (task_nblk_[t] == 1 && h.rc == 16 && h.nsrc >= split_sources_) return h.nsrc > split8_sources_ ? 3 : 2;
+            const int tile = task_tile_[(size_t)t] ? 1 : 0;
+            if (task_nblk_[t] == 1 && h.rc == 16 && h.nsrc >= split_sources_) return (h.nsrc > split8_sources_ ? 5 : 3) + tile;
+            if (tile) return 2;
             for (i64 b = task_first_blk_[t]; b < task_first_blk_[t] + task_nblk_[t]; ++b)
                 if (P_.hdr[b].rc == 16) return 1;
             return 0;
@@ -1141,9 +1409,9 @@ class Builder {
             P_.block_record.assign(nblocks + 1, 0);
             std::vector<int> waves(nblocks, 1);
             for (i64 l = 0; l < nlev; ++l)
-                for (int c = 2; c < NC; ++c)
+                for (int c = 3; c < NC; ++c)
                     for (i64 t = P_.level_class_ptr[NC * l + c]; t < P_.level_class_ptr[NC * l + c + 1]; ++t)
-                        waves[P_.task_ptr[t]] = c == 2 ? 4 : 8;  // split classes: one block per task
+                        waves[P_.task_ptr[t]] = c <= 4 ? 4 : 8;  // split classes: one block per task
             for (i64 b = 0; b < nblocks; ++b) P_.block_record[b + 1] = P_.block_record[b] + waves[b] * BlockProgram::record_lines(waves[b]);
             P_.prologue.assign((size_t)(P_.block_record[nblocks] + 1) * LW, 0);  // one spare line: the kernels load whole records
             for (i64 b = 0; b < nblocks; ++b) {
@@ -1183,6 +1451,14 @@ class Builder {
         std::vector<ClusterHeader> ch(nclusters);
         for (i64 c = 0; c < nclusters; ++c) ch[cfill[cluster_level_[c]]++] = P_.clusters[c];
         P_.clusters.swap(ch);
+        // wide items, by level (emission order kept inside a level: the items of one chain stay together)
+        P_.item_level_ptr.assign(nlev + 1, 0);
+        for (int32_t l : item_level_) P_.item_level_ptr[l + 1]++;
+        for (i64 l = 0; l < nlev; ++l) P_.item_level_ptr[l + 1] += P_.item_level_ptr[l];
+        std::vector<i64> ifill(P_.item_level_ptr.begin(), P_.item_level_ptr.end() - 1);
+        std::vector<WideItem> sorted(P_.items.size());
+        for (size_t k = 0; k < P_.items.size(); ++k) sorted[(size_t)ifill[item_level_[k]]++] = P_.items[k];
+        P_.items.swap(sorted);
     }
 
     const GatherForm &G_;
@@ -1199,7 +1475,14 @@ class Builder {
     std::vector<int32_t> order_, rank_;  // push_block: distinct source positions and their ranks
     // emit_big_chain: private scratch of the threads that rank the groups of a chain
     i64 emit_threads_ = 0;
-    RankedGroup chain_group_;
+    i64 item_rows_ = kItemRows, sort_rows_ = 1, item_min_sources_ = kItemMinSources;
+    double item_min_fill_ = 0.5;        // an item's tiles must use at least this share of its union list, on average
+    std::vector<char> task_tile_;       // per block task: 1 = a row tile of a wide item
+    std::vector<int32_t> item_level_;   // per item, in emission order
+    RankedGroup chain_groups_[4];
+    std::vector<int32_t> item_union_, item_perm_, item_map_;  // append_item scratch
+    std::vector<uint8_t> item_mask_, item_kmask_;
+    std::vector<i64> item_kfirst_;
     std::vector<std::vector<i64>> tstamp_;
     std::vector<std::vector<int32_t>> trank_;
     std::vector<i64> tstamp_id_;
@@ -1280,9 +1563,14 @@ BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int c
     return b.run();
 }
 
-ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P)
+ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P, bool items_view)
 {
     ProgramReport R;
+    constexpr int NC = BlockProgram::kClasses;
+    if ((i64)P.level_class_ptr.size() != NC * ((i64)P.level_ptr.size() - 1) + 1 || P.item_level_ptr.size() != P.level_ptr.size()) {
+        R.bad_index = 1;
+        return R;
+    }
     const i64 n = G.n;
     // synthetic right-hand side and the sequential answer
     std::vector<double> b(n), want(n);
@@ -1406,8 +1694,66 @@ ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P)
                 writes[id]++;
             }
         }
+        // ---- wide items of this level (the items view; the tile view runs them as the blocks of classes 2, 4, 6) ----
+        for (i64 k = P.item_level_ptr[l]; items_view && k < P.item_level_ptr[l + 1]; ++k) {
+            const WideItem &I = P.items[k];
+            const i64 nr = 16 * (i64)I.m_tiles, ns = 4 * (i64)I.k_steps, nwin = ((i64)I.k_steps + 15) / 16;
+            if (I.m_tiles < 1 || I.m_tiles > 4 || I.k_steps < 0 || I.ids_off < 0 || I.ids_off + 2 * nr + ns > (i64)P.src_idx.size() || I.mask_off < 0 ||
+                I.mask_off + 4 * nwin > (i64)P.item_masks.size() || I.coef_off < 0) {
+                ++R.bad_index;
+                continue;
+            }
+            const int32_t *ids = P.src_idx.data() + I.ids_off;
+            const uint32_t *mw = P.item_masks.data() + I.mask_off;
+            std::vector<double> acc((size_t)nr, 0.0);
+            for (i64 r = 0; r < nr; ++r) {
+                const int32_t id = ids[nr + r];
+                if (id == BlockProgram::kNone) continue;
+                if (!valid(id)) { ++R.bad_index; continue; }
+                if (id < 0 && done(id) >= l) ++R.order_violations;
+                acc[(size_t)r] = value(id);
+            }
+            // replay of dev::solve_items: the blocks of a K-step follow those of the K-step before; the window words give the
+            // masks and the number of blocks before each window
+            i64 blk = 0;
+            bool ok = true;
+            for (i64 k = 0; k < I.k_steps && ok; ++k) {
+                if (k % 16 == 0 && (i64)mw[4 * (k / 16) + 2] != blk) { ++R.bad_index; ok = false; break; }
+                const unsigned mask = (mw[4 * (k / 16) + ((k % 16) >= 8 ? 1 : 0)] >> (4 * (k % 8))) & 15u;
+                if (mask >> I.m_tiles) { ++R.bad_index; ok = false; break; }
+                for (int q = 0; q < I.m_tiles; ++q) {
+                    if (!((mask >> q) & 1u)) continue;
+                    if (I.coef_off + (blk + 1) * 64 > (i64)P.coef.size()) { ++R.bad_index; ok = false; break; }
+                    const double *cb = P.coef.data() + I.coef_off + blk * 64;
+                    ++blk;
+                    for (int gsrc = 0; gsrc < 4; ++gsrc) {
+                        const int32_t id = ids[2 * nr + 4 * k + gsrc];
+                        if (!valid(id)) { ++R.bad_index; continue; }
+                        bool zero = true;
+                        for (int r = 0; r < 16; ++r) zero = zero && cb[gsrc * 16 + r] == 0.0;
+                        if (!zero && done(id) >= l) ++R.order_violations;  // (an item never reads what its own level writes)
+                        for (int r = 0; r < 16; ++r) acc[(size_t)(16 * q + r)] -= cb[gsrc * 16 + r] * value(id);
+                    }
+                }
+            }
+            if (!ok) continue;
+            for (i64 r = 0; r < nr; ++r) {
+                const int32_t id = ids[r];
+                if (id == BlockProgram::kNone) continue;
+                if (!valid(id)) { ++R.bad_index; continue; }
+                value(id) = acc[(size_t)r];
+                done(id) = l;
+                if (id >= 0) writes[id]++;
+                producer(id) = -3;
+            }
+        }
         // ---- block tasks of this level ----
         for (i64 t = P.level_ptr[l]; t < P.level_ptr[l + 1]; ++t) {
+            if (items_view) {  // classes 2, 4, 6: row tiles of the items above
+                int c = 0;
+                while (c + 1 < NC && t >= P.level_class_ptr[NC * l + c + 1]) ++c;
+                if (c == 2 || c == 4 || c == 6) continue;
+            }
             for (i64 bk = P.task_ptr[t]; bk < P.task_ptr[t + 1]; ++bk) {
                 const BlockHeader &h = P.hdr[bk];
                 const int rc = h.rc;

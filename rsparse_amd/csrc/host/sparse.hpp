@@ -161,9 +161,28 @@ struct GroupRec {       // 64 bytes: four 16-byte loads, the same address in eve
     int32_t flags;      // bits 0-2: number of valid entries (0..4); kFirst: start of an unknown; kLast: divide and store
     static constexpr int32_t kFirst = 8, kLast = 16;
 };
+// A WIDE ITEM: up to 64 unknowns of one chain phase (4 row tiles of 16, each tile one ranked 16-row group) over the UNION of
+// the tiles' source lists,
+//     OUT[r] = INIT[r] - sum_e A[r][e] * IN[e].
+// A 4-bit mask per K-step (4 sources) names the row tiles that have entries in it; only those 16 x 4 coefficient BLOCKS are
+// stored (64 doubles each: lane i + 16 g <-> A[16 t + i][4 k_step + g]), K-step by K-step, tiles ascending.  Executed by
+// dev::solve_items (64 x 64 register tiles) on the levels that fill the chip; the same arithmetic exists as ordinary
+// 16-row blocks (the item's TWINS, task classes 2 / 4 / 6), which is how latency-bound levels and narrow blocks run it.
+struct WideItem {          // 32 bytes
+    int32_t m_tiles;       // 1..4
+    int32_t k_steps;       // sources / 4 (the list is padded to a multiple of 16 sources, as for blocks)
+    i64 coef_off;          // into coef: the item's first block
+    i64 ids_off;           // into src_idx: [16 m_tiles destination ids][16 m_tiles initial-value ids][4 k_steps source ids]
+    i64 mask_off;          // into item_masks: 4 words per window of 16 K-steps: the masks (4 bits per K-step, two words), the number of
+                           // coefficient blocks before the window, 0
+};
 struct BlockProgram {
     static constexpr int32_t kNone = INT32_MIN;
-    static constexpr int kClasses = 4;
+    // task classes inside a level, in task order: 0 vector-path blocks only; 1 one wavefront per (task, 64 columns), at least one
+    // matrix-core block; 3 / 5 one matrix-core block whose sources are split over 4 / 8 wavefronts; 2, 4, 6: the same three
+    // for blocks that are TWINS OF WIDE ITEMS (one block per task), so that a level can run its items either as items
+    // (dev::solve_items; the block kernel then skips classes 2, 4, 6) or as blocks (classes 1+2, 3+4, 5+6 are contiguous)
+    static constexpr int kClasses = 7;
     std::vector<BlockHeader> hdr;    // per block
     // pools
     std::vector<int32_t> src_idx;    // id >= 0: row of X; id < 0 (and != kNone): scratch row ~id
@@ -208,12 +227,14 @@ struct BlockProgram {
     // schedule
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
     std::vector<i64> level_ptr;      // block tasks of level l
-    std::vector<i64> level_class_ptr;  // kClasses entries per level: tasks of class 0 (vector-path blocks only), 1 (one
-                                       // wavefront per task and 64 columns, matrix-core blocks), 2 (4 wavefronts share
-                                       // the block's sources), 3 (8 wavefronts)
+    std::vector<i64> level_class_ptr;  // kClasses entries per level (see kClasses)
+    std::vector<WideItem> items;       // sorted by level
+    std::vector<uint32_t> item_masks;
+    std::vector<i64> item_level_ptr;   // items of level l
     std::vector<i64> cluster_level_ptr;  // clusters of level l (same level numbering)
     i64 scratch_rows = 0;
     i64 big_chains = 0, inverted_rows = 0, padded_entries = 0, cluster_rows = 0, cluster_entries = 0;
+    i64 item_padded_entries = 0;     // multiply-adds (per right-hand side) of the items view: 256 per (K-step, row tile) with entries
     // REFILL RECIPE: where every value of the programme comes from, so that new values on the same pattern (a
     // refactorisation) are poured into coef and groups without emitting the programme again (refill_block_program).
     // A source code is -1 (a constant: padding, the -1 of a partial-sum combine), an entry of the gather form
@@ -240,6 +261,8 @@ struct BlockProgram {
 // false if the programme carries no valid recipe
 bool refill_block_program(const GatherForm &G, BlockProgram &P);
 constexpr i64 kBigChain = 24;        // chains longer than this are replaced by their inverse
+constexpr i64 kItemRows = 64;        // unknowns per wide item of a chain (32, 48 or 64; 16: no items)
+constexpr i64 kItemMinSources = 256; // ... only over row groups with at least this many sources (shorter ones stay plain blocks)
 constexpr i64 kMaxChain = 1024;      // ... in pieces of at most this many unknowns (host cost O(w^3) per piece)
 constexpr i64 kSplitSources = 64;    // matrix-core blocks with at least this many sources are split over 4 wavefronts,
                                      // with more than 4x this over 8
@@ -326,7 +349,8 @@ struct ProgramReport {
     i64 unwritten = 0;        // unknowns no block or cluster writes, or written more than once
     double max_rel_error = 0; // against sequential substitution
 };
-ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P);
+// items_view: the wide items run as items (dev::solve_items) instead of as their row tiles
+ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P, bool items_view = false);
 ProgramReport check_supernodal_program(const GatherForm &R, const SnProgram &P);
 
 }  // namespace rsp

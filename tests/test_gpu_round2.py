@@ -490,6 +490,7 @@ def test_shared_handle_on_two_streams():
 
 # ---- every kernel variant an environment switch selects, against the oracle ------------------------------------------
 
+ITEMS_EVERYWHERE = {"RSP_ITEM_WAVES": "1", "RSP_ITEM_MIN_SOURCES": "1", "RSP_ITEM_MIN_FILL": "0"}
 VARIANTS = [
     {},                                                   # defaults
     {"RSP_LEAN_WGS": "1"},                                # every level through the lean variant
@@ -503,8 +504,14 @@ VARIANTS = [
     {"RSP_TRI_SINGLE": "1"},                              # ... for one right-hand side
     {"RSP_SPLIT_SOURCES": "32", "RSP_SPLIT8_SOURCES": "64", "RSP_MAX_BLOCK_SOURCES": "128"},  # more split blocks, partial sums
     {"RSP_TASK_BLOCKS": "3"},                             # several dependent blocks per wavefront (long unsplit blocks)
-    {"RSP_MERGED": "1"},                                  # narrow blocks: runs of deep-ring levels as one launch each
-    {"RSP_MERGED": "1", "RSP_LEAN_WGS": "1000000"},       # ... every level deep-ring: the longest runs
+    # round 3: wide items over every chain (however short and sparse), run as items (64 x 64 register tiles) on every level
+    {**ITEMS_EVERYWHERE},
+    {**ITEMS_EVERYWHERE, "RSP_ITEM_KS": "2"},             # ... K-steps of an item shared by two wavefronts
+    {**ITEMS_EVERYWHERE, "RSP_ITEM_KS": "4"},             # ... by four
+    {**ITEMS_EVERYWHERE, "RSP_ITEM_WAVES": "0"},          # ... emitted but never run: always the twin 16-row blocks
+    {**ITEMS_EVERYWHERE, "RSP_ITEM_ROWS": "32"},          # items of two row tiles
+    {**ITEMS_EVERYWHERE, "RSP_SORT_ROWS": "0", "RSP_MAX_BLOCK_SOURCES": "64"},  # rows in natural order, items over partial sums
+    {"RSP_ITEM_ROWS": "16"},                              # no items at all
 ]
 
 
@@ -542,36 +549,37 @@ def test_every_switch_variant_vs_oracle(env, monkeypatch):
     assert rel_inf(X.cpu().numpy()[:, [0, 100, 191]], want) <= REL_X
 
 
-def test_merged_level_launches_repeat(monkeypatch):
-    """RSP_MERGED=1: several levels per launch, workgroups of a level waiting on the flags of the previous one.  A
-    deeper factor than the variant test's, many solves in a row on one handle (the epoch in the flag words advances with
-    every launch), 1 and 16 columns, against the oracle; the host entry point reports no abandoned wait."""
+def test_wide_items_vs_oracle(monkeypatch):
+    """The wide items (dev::solve_items) on a deeper factor than the variant test's: every level with items runs them as
+    items, 64 / 128 / 256 columns (one to four chunks per workgroup), both sweeps, against the oracle on spread columns and
+    against the same handle's twin-block path (RSP_ITEM_WAVES=0 builds nothing new: the choice is made per launch)."""
     torch = _torch()
-    monkeypatch.setenv("RSP_MERGED", "1")
+    monkeypatch.setenv("RSP_ITEM_MIN_SOURCES", "1")  # (read when the programme is built: items over every chain)
+    monkeypatch.setenv("RSP_ITEM_MIN_FILL", "0")
     A = synth.laplacian_2d(160, 160)
     n = A[0]
-    F = rs.CholHandle(A, rs.schol(A, 0))
-    stream = torch.cuda.current_stream().cuda_stream
-    b = 2.0 * synth.splitmix64(5, n) - 1.0
-    st, want = orc.cholsol(A, b.copy(), 0)
+    st, L = orc.chol(A, orc.schol(A, 0))
     assert st == orc.OK
-    for rep in range(6):
-        x = torch.tensor(b, device="cuda:0")
-        F.solve_dev(x.data_ptr(), rs.api.COL_MAJOR, n, 1, True, stream)
-        torch.cuda.synchronize()
-        assert rel_inf(x.cpu().numpy(), want) <= REL_X, rep
-    X = torch.tensor(np.stack([b * (c + 1) for c in range(16)], axis=1).copy(), device="cuda:0")
-    F.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, 16, 16, True, stream)
-    torch.cuda.synchronize()
-    assert rel_inf(X.cpu().numpy()[:, 15], 16.0 * want) <= REL_X
-    h = b.copy()
-    F.solve(h)  # host entry point: checks the sticky failure word after its synchronisation
-    assert rel_inf(h, want) <= REL_X
+    stream = torch.cuda.current_stream().cuda_stream
+    for kind, name in ((0, "lsolve"), (1, "ltsolve")):
+        h = rs.TriHandle(L, kind)
+        for nrhs in (64, 128, 256):
+            Bh = (2.0 * synth.splitmix64(300 + nrhs, n * nrhs) - 1.0).reshape(n, nrhs)
+            cols = sorted({0, 1, 33, 63, nrhs // 2, nrhs - 1})
+            want = np.stack([orc.trisolve(name, L, Bh[:, c].copy()) for c in cols], axis=1)
+            got = {}
+            for waves in ("1", "0"):
+                monkeypatch.setenv("RSP_ITEM_WAVES", waves)
+                X = torch.tensor(Bh, device="cuda:0")
+                h.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, nrhs, nrhs, stream)
+                torch.cuda.synchronize()
+                got[waves] = X.cpu().numpy()
+                assert rel_inf(got[waves][:, cols], want) <= REL_X, (name, nrhs, waves)
+            assert rel_inf(got["1"], got["0"]) <= 1e-12, (name, nrhs)
+        info = h.info()
+        assert info["items"] > 0, info
 
 
-@pytest.mark.parametrize("env", [{"RSP_CHOL_GROUPED": "0"}, {"RSP_CHOL_TINY": "0"}, {"RSP_CHOL_FUSE_WAVES": "0"}, {"RSP_CHOL_FUSE_WAVES": "100000"},
-                                 {"RSP_CHOL_SHORT_GROUPS": "0"}, {"RSP_CHOL_BLOCK_PANELS": "1"}],
-                         ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_every_cholesky_variant_vs_oracle(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
