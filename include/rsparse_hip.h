@@ -231,6 +231,16 @@ void rsp_chol_free(rsp_chol *F);
 
 /* rsparse::cholsol (src/lib.rs:377-389): b overwritten with A\b */
 int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
+/* The analysis cache behind rsp_cholsol_f64 (no counterpart in the reference, whose cholsol, lib.rs:377-389, carries no handle
+ * and repeats ordering and symbolic analysis on every call): after a call with a new pattern, a background thread of the
+ * library analyses that pattern as a multi-use handle; later calls with the same (device, n, order, pattern of A) --
+ * compared entry by entry -- refactorise on it and solve (C2: 1.7 s -> tens of milliseconds).  RSP_ANALYSIS_CACHE = number
+ * of patterns kept (default 2, 0 switches the cache off), RSP_ANALYSIS_CACHE_MB = device memory they may hold (default
+ * 16384); least recently used entries leave first.  rsp_cache_stats: out[0..6] = hits, misses, entries, estimated device
+ * bytes, background analyses in flight, inserted, evicted.  rsp_cache_clear waits for the background analyses and frees
+ * every cached handle (call it before the process ends if device memory must be returned in an orderly way). */
+int rsp_cache_stats(int64_t *out);
+int rsp_cache_clear(void);
 /* cholsol over `nsys` systems that share ONE pattern (A->p, A->i; A->x is ignored) and differ in their values:
  * Ax_all[s * nnz .. ) are the values of system s in A's entry order, B[s * n .. ) its right-hand side, overwritten
  * by the solution.  What the reference does by calling cholsol (lib.rs:377-389) in a loop -- BASELINE.json's batched

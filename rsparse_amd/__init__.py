@@ -22,6 +22,8 @@ from .api import (  # noqa: F401
     validate_program,
     validate_refill,
     validate_supernodal,
+    cache_stats,
+    cache_clear,
     amd,
     chol,
     cholsol,

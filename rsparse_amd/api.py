@@ -72,6 +72,8 @@ def lib():
             "rsp_tri_validate_refill": (cint, [csc, vp, cint, i64, cint, vp]),
             "rsp_tri_program_checksum": (cint, [csc, cint, i64, cint, vp]),
             "rsp_tri_validate_supernodal": (cint, [csc, cint, vp, vp, vp]),
+            "rsp_cache_stats": (cint, [vp]),
+            "rsp_cache_clear": (cint, []),
             "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
             "rsp_schol": (cint, [csc, C.c_int8, C.POINTER(vp)]),
             "rsp_sqr_qr": (cint, [csc, C.c_int8, C.POINTER(vp)]),
@@ -555,6 +557,17 @@ def program_checksum(t, kind, task_blocks=0, cluster_slots=0):
     out = np.zeros(4, np.uint64)
     _check(lib().rsp_tri_program_checksum(C.byref(t._view()), kind, task_blocks, cluster_slots, out.ctypes.data))
     return tuple(int(v) for v in out)
+
+
+def cache_stats():
+    """The analysis cache behind cholsol (rsp_cache_stats)."""
+    a = np.zeros(7, np.int64)
+    _check(lib().rsp_cache_stats(a.ctypes.data))
+    return dict(zip(("hits", "misses", "entries", "bytes", "pending", "inserted", "evicted"), a.tolist()))
+
+
+def cache_clear():
+    _check(lib().rsp_cache_clear())
 
 
 def validate_supernodal(t, kind, task_slots=0, small_node=0, max_node=0, max_item_k=0):

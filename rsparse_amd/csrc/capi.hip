@@ -70,6 +70,7 @@ struct rsp_lu {
     std::unique_ptr<TriSolver> lower, upper;  // built on first solve
     bool single_use = false;                  // lusol: one solve, then dropped
     DeviceBuffer<int64_t> d_pinv, d_q;        // rsp_lu_solve_dev_f64: the two permutations on the device
+    std::vector<int64_t> q_host;              // ... and what d_q holds
     DeviceBuffer<double> work;
     UseGuard guard;
 };
@@ -250,6 +251,7 @@ int rsp_tri_solve_pair_dev_f64(rsp_tri *first, rsp_tri *second, double *dX, int6
 int rsp_tri_info(const rsp_tri *h, int64_t *info)
 {
     if (!h || !info) return RSP_BAD_INPUT;
+    std::lock_guard<std::mutex> lock(const_cast<rsp_tri *>(h)->guard.m);
     const TriSolver &s = h->solver;
     const TriProgram &P = s.multi_program();
     info[0] = s.n();
@@ -593,6 +595,7 @@ int rsp_chol_refine_dev_f64(rsp_chol *F, const rsp_mat *M, const double *dB, dou
     if (nrhs == 0 || n == 0) return RSP_OK;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(F->guard.m);
+        if (!F->f.valid()) return (int)RSP_NOT_POSITIVE_DEFINITE;
         hipStream_t st = (hipStream_t)stream;
         F->guard.begin(st);
         const int64_t rows = layout == RSP_ROW_MAJOR ? n : nrhs, cols = layout == RSP_ROW_MAJOR ? nrhs : n;
@@ -753,7 +756,10 @@ int rsp_chol_refactor_f64(rsp_chol *F, const rsp_csc_f64 *A)
     if (!F || !sane(A) || A->m != A->n || A->n != F->f.n() || A->p[A->n] != F->f.annz()) return RSP_BAD_INPUT;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(F->guard.m);
-        return F->f.factorize(view_of(A));  // same analysis, same launches; the solve programmes are rebuilt on the next solve
+        // the values are scattered through the analysed pattern's maps: another pattern of the same size would give a wrong
+        // factor without any error
+        if (pattern_hash(view_of(A)) != F->f.pattern()) return (int)RSP_BAD_INPUT;
+        return F->f.factorize(view_of(A));  // same analysis, same launches; the solve programmes receive the values on the next solve
     });
 }
 
@@ -771,6 +777,8 @@ int rsp_chol_get_factor(const rsp_chol *F, int64_t *Lp, uint64_t *Li, double *Lx
 {
     if (!F || !Lp || !Li || !Lx) return RSP_BAD_INPUT;
     return guarded([&] {
+        std::lock_guard<std::mutex> lock(const_cast<rsp_chol *>(F)->guard.m);
+        if (!F->f.valid()) return (int)RSP_NOT_POSITIVE_DEFINITE;  // the last (re)factorisation failed
         F->f.download(Lp, reinterpret_cast<int64_t *>(Li), Lx);
         return (int)RSP_OK;
     });
@@ -781,6 +789,7 @@ int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs)
     if (!F || !B || nrhs < 0 || ldb < F->f.n()) return RSP_BAD_INPUT;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(F->guard.m);
+        if (!F->f.valid()) return (int)RSP_NOT_POSITIVE_DEFINITE;  // the last (re)factorisation failed: nothing to solve with
         F->f.solve_host(B, ldb, nrhs);
         return (int)RSP_OK;
     });
@@ -792,6 +801,7 @@ int rsp_chol_solve_dev_f64(rsp_chol *F, double *dB, int layout, int64_t ld, int6
     if (layout == RSP_COL_MAJOR ? ld < F->f.n() : ld < nrhs) return RSP_BAD_INPUT;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(F->guard.m);
+        if (!F->f.valid()) return (int)RSP_NOT_POSITIVE_DEFINITE;
         F->guard.begin((hipStream_t)stream);
         F->f.solve_device(dB, layout, ld, nrhs, permute != 0, (hipStream_t)stream);
         F->guard.end((hipStream_t)stream);
@@ -804,6 +814,8 @@ int64_t rsp_chol_lnz(const rsp_chol *F) { return F ? F->f.lnz() : 0; }
 int rsp_chol_factor_view(const rsp_chol *F, const int64_t **Lp, const uint64_t **Li, const double **dLx)
 {
     if (!F || !Lp || !Li || !dLx) return RSP_BAD_INPUT;
+    std::lock_guard<std::mutex> lock(const_cast<rsp_chol *>(F)->guard.m);
+    if (!F->f.valid()) return RSP_NOT_POSITIVE_DEFINITE;
     *Lp = F->f.host_Lp();
     *Li = reinterpret_cast<const uint64_t *>(F->f.host_Li());
     *dLx = F->f.device_Lx();
@@ -813,6 +825,7 @@ int rsp_chol_factor_view(const rsp_chol *F, const int64_t **Lp, const uint64_t *
 int rsp_chol_info(const rsp_chol *F, int64_t *info)
 {
     if (!F || !info) return RSP_BAD_INPUT;
+    std::lock_guard<std::mutex> lock(const_cast<rsp_chol *>(F)->guard.m);
     F->f.info(info);
     return RSP_OK;
 }
@@ -821,13 +834,245 @@ double rsp_chol_factor_ms(const rsp_chol *F) { return F ? F->f.factor_ms() : 0.0
 
 void rsp_chol_free(rsp_chol *F) { delete F; }
 
+// ---- analysis cache behind the one-shot signature --------------------------------------------------------
+// The reference's cholsol(a, b, order) (lib.rs:377-389) carries no handle: a caller that solves with ONE pattern again and
+// again (time stepping, Newton iterations) would pay ordering + symbolic analysis + programme emission on every call.
+// rsp_cholsol_f64 therefore keeps the analysed handles of the last few patterns: after a call that missed, a background
+// thread analyses the pattern again as a MULTI-USE handle (blocked solve programmes emitted ahead of the values) and puts
+// it into the cache; later calls with the same (device, n, order, pattern) -- compared entry by entry, not by hash alone --
+// refactorise on that analysis and solve, nothing else.  Least recently used entries leave when the entry or byte budget
+// is exceeded (RSP_ANALYSIS_CACHE entries, default 2, 0 = off; RSP_ANALYSIS_CACHE_MB device memory, default 16384).
+// An entry is taken OUT of the cache while a call uses it, so two threads never share a handle; the second thread of a
+// pair takes the plain path.  The results of a hit and of a miss differ only by the order of the solves' additions.
+extern "C++" {
+namespace {
+struct CholCacheEntry {
+    uint64_t hash = 0;
+    int device = 0;
+    int8_t order = 0;
+    int64_t n = 0, nnz = 0;
+    std::vector<int64_t> p, i;  // the pattern itself: a hit is verified entry by entry
+    std::unique_ptr<rsp_symb> S;
+    std::unique_ptr<rsp_chol> F;
+    int64_t bytes = 0;  // estimate of the device memory behind F
+    uint64_t stamp = 0;
+};
+struct CholCache {
+    std::mutex m;
+    std::vector<std::unique_ptr<CholCacheEntry>> entries;
+    std::vector<uint64_t> pending;  // hashes a background analysis is running for
+    std::vector<std::thread> workers;
+    uint64_t clock = 0;
+    int64_t hits = 0, misses = 0, inserted = 0, evicted = 0;
+    ~CholCache()
+    {
+        for (std::thread &t : workers)
+            if (t.joinable()) t.join();
+        // the process is ending: the HIP runtime may already be gone, the handles' device memory goes with the process
+        for (auto &e : entries) {
+            (void)e->F.release();
+            (void)e->S.release();
+        }
+    }
+};
+CholCache &chol_cache()
+{
+    static CholCache c;
+    return c;
+}
+int64_t cache_env(const char *name, int64_t fallback)
+{
+    const char *e = getenv(name);
+    return e ? std::atoll(e) : fallback;
+}
+int64_t chol_cache_capacity() { return std::max<int64_t>(0, cache_env("RSP_ANALYSIS_CACHE", 2)); }
+int64_t chol_cache_budget() { return std::max<int64_t>(0, cache_env("RSP_ANALYSIS_CACHE_MB", 16384)) << 20; }
+
+bool same_pattern(const CholCacheEntry &e, const rsp_csc_f64 *A)
+{
+    return e.n == A->n && e.nnz == A->p[A->n] && std::memcmp(e.p.data(), A->p, (size_t)(A->n + 1) * sizeof(int64_t)) == 0 &&
+           std::memcmp(e.i.data(), A->i, (size_t)e.nnz * sizeof(int64_t)) == 0;
+}
+
+// entries beyond the budgets leave, least recently used first (the caller holds the cache's mutex); returns what must be freed
+// OUTSIDE the lock (freeing a handle synchronises the device)
+std::vector<std::unique_ptr<CholCacheEntry>> chol_cache_trim(CholCache &C, int64_t capacity, int64_t budget)
+{
+    std::vector<std::unique_ptr<CholCacheEntry>> out;
+    auto total = [&] {
+        int64_t b = 0;
+        for (auto &e : C.entries) b += e->bytes;
+        return b;
+    };
+    while (!C.entries.empty() && ((int64_t)C.entries.size() > capacity || total() > budget)) {
+        size_t oldest = 0;
+        for (size_t k = 1; k < C.entries.size(); ++k)
+            if (C.entries[k]->stamp < C.entries[oldest]->stamp) oldest = k;
+        out.push_back(std::move(C.entries[oldest]));
+        C.entries.erase(C.entries.begin() + (long)oldest);
+        C.evicted++;
+    }
+    return out;
+}
+
+// background job of a miss: the multi-use analysis of the pattern (no values needed: the first hit brings them)
+void chol_cache_analyse(std::unique_ptr<CholCacheEntry> e)
+{
+    CholCache &C = chol_cache();
+    const uint64_t hash = e->hash;
+    bool ok = false;
+    try {
+        if (hipSetDevice(e->device) == hipSuccess) {
+            CscView A{e->n, e->n, e->p.data(), e->i.data(), nullptr};
+            e->S.reset(new rsp_symb);
+            e->S->s = symbolic_cholesky(A, e->order);
+            e->F.reset(new rsp_chol);
+            ok = e->F->f.analyze(A, e->S->s, false) == kOk;
+            if (ok) e->F->f.finish_analysis();  // the solve programmes are emitted too: the first hit finds everything ready
+            e->bytes = e->S->s.lnz * 48 + e->nnz * 24;
+        }
+    } catch (...) {
+        ok = false;
+    }
+    std::vector<std::unique_ptr<CholCacheEntry>> dead;
+    {
+        std::lock_guard<std::mutex> lock(C.m);
+        C.pending.erase(std::remove(C.pending.begin(), C.pending.end(), hash), C.pending.end());
+        if (ok && e->bytes <= chol_cache_budget() && chol_cache_capacity() > 0) {
+            e->stamp = ++C.clock;
+            C.entries.push_back(std::move(e));
+            C.inserted++;
+            dead = chol_cache_trim(C, chol_cache_capacity(), chol_cache_budget());
+        }
+    }
+    dead.clear();
+    e.reset();
+}
+}  // namespace
+}  // extern "C++"
+
+int rsp_cache_clear(void)
+{
+    return guarded([&] {
+        CholCache &C = chol_cache();
+        std::vector<std::thread> workers;
+        {
+            std::lock_guard<std::mutex> lock(C.m);
+            workers.swap(C.workers);
+        }
+        for (std::thread &t : workers)
+            if (t.joinable()) t.join();
+        std::vector<std::unique_ptr<CholCacheEntry>> dead;
+        {
+            std::lock_guard<std::mutex> lock(C.m);
+            dead.swap(C.entries);
+        }
+        dead.clear();
+        return (int)RSP_OK;
+    });
+}
+
+int rsp_cache_stats(int64_t *out)
+{
+    if (!out) return RSP_BAD_INPUT;
+    CholCache &C = chol_cache();
+    std::lock_guard<std::mutex> lock(C.m);
+    out[0] = C.hits;
+    out[1] = C.misses;
+    out[2] = (int64_t)C.entries.size();
+    out[3] = 0;
+    for (auto &e : C.entries) out[3] += e->bytes;
+    out[4] = (int64_t)C.pending.size();
+    out[5] = C.inserted;
+    out[6] = C.evicted;
+    return RSP_OK;
+}
+
 int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
 {
     if (!sane_indices(A) || !b || A->m != A->n) return RSP_BAD_INPUT;
-    rsp_symb *S = nullptr;
-    rsp_chol *F = nullptr;
     const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = clock();
+    // ---- the analysis cache: same pattern as an earlier call? ----
+    const int64_t capacity = chol_cache_capacity();
+    uint64_t hash = 0;
+    int device = 0;
+    bool spawn = false;
+    if (capacity > 0 && A->n > 0) {
+        int st = guarded([&] {
+            if (int rd = require_device()) return rd;
+            RSP_HIP(hipGetDevice(&device));
+            return (int)RSP_OK;
+        });
+        if (st != RSP_OK) return st;
+        hash = pattern_hash(view_of(A));
+        CholCache &C = chol_cache();
+        std::unique_ptr<CholCacheEntry> hit;
+        {
+            std::lock_guard<std::mutex> lock(C.m);
+            for (size_t k = 0; k < C.entries.size(); ++k) {
+                CholCacheEntry &e = *C.entries[k];
+                if (e.hash == hash && e.device == device && e.order == order && e.n == A->n && e.nnz == A->p[A->n]) {
+                    hit = std::move(C.entries[k]);  // out of the cache while this call uses it
+                    C.entries.erase(C.entries.begin() + (long)k);
+                    break;
+                }
+            }
+        }
+        if (hit && !same_pattern(*hit, A)) {  // a hash collision: not this pattern, back it goes
+            std::lock_guard<std::mutex> lock(C.m);
+            C.entries.push_back(std::move(hit));
+            hit.reset();
+        }
+        if (hit) {
+            st = rsp_chol_refactor_f64(hit->F.get(), A);  // numeric Cholesky on the cached analysis (GPU)
+            const double t1 = clock();
+            if (st == RSP_OK) st = rsp_chol_solve_f64(hit->F.get(), b, A->n, 1);  // P, lsolve, ltsolve, P' through the resident programmes
+            if (getenv("RSP_TIMING")) fprintf(stderr, "cholsol (cached analysis): refactor %.3fs, solve %.3fs\n", t1 - t0, clock() - t1);
+            std::vector<std::unique_ptr<CholCacheEntry>> dead;
+            {
+                std::lock_guard<std::mutex> lock(C.m);
+                C.hits++;
+                hit->stamp = ++C.clock;
+                C.entries.push_back(std::move(hit));
+                dead = chol_cache_trim(C, capacity, chol_cache_budget());
+            }
+            return st;
+        }
+        {
+            std::lock_guard<std::mutex> lock(C.m);
+            C.misses++;
+            // one background analysis per pattern, a few at a time
+            spawn = std::find(C.pending.begin(), C.pending.end(), hash) == C.pending.end() && C.pending.size() < 2;
+            if (spawn) C.pending.push_back(hash);
+        }
+    }
+    std::thread worker;
+    if (spawn) {
+        // the pattern is copied (the caller's arrays are only borrowed) and analysed beside this call's own work
+        std::unique_ptr<CholCacheEntry> e(new CholCacheEntry);
+        e->hash = hash;
+        e->device = device;
+        e->order = order;
+        e->n = A->n;
+        e->nnz = A->p[A->n];
+        bool copied = true;
+        try {
+            e->p.assign(A->p, A->p + A->n + 1);
+            e->i.assign(reinterpret_cast<const int64_t *>(A->i), reinterpret_cast<const int64_t *>(A->i) + e->nnz);
+            CholCacheEntry *raw = e.release();
+            worker = std::thread([raw] { chol_cache_analyse(std::unique_ptr<CholCacheEntry>(raw)); });
+        } catch (...) {
+            copied = false;
+        }
+        if (!copied) {
+            std::lock_guard<std::mutex> lock(chol_cache().m);
+            auto &pend = chol_cache().pending;
+            pend.erase(std::remove(pend.begin(), pend.end(), hash), pend.end());
+        }
+    }
+    rsp_symb *S = nullptr;
+    rsp_chol *F = nullptr;
     int st = rsp_schol(A, order, &S);                    // ordering and symbolic analysis (host)
     const double t1 = clock();
     if (st == RSP_OK) st = chol_factor_impl(A, S, &F, true);  // numeric Cholesky (GPU); one solve, then the factor is dropped
@@ -837,6 +1082,16 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     const double t3 = clock();
     rsp_chol_free(F);
     rsp_symb_free(S);
+    if (worker.joinable()) {
+        std::lock_guard<std::mutex> lock(chol_cache().m);
+        auto &ws = chol_cache().workers;
+        ws.push_back(std::move(worker));
+        if (ws.size() > 4) {  // the oldest job has long finished (at most two run at a time): collect it, so the list stays short
+            std::thread old = std::move(ws.front());
+            ws.erase(ws.begin());
+            if (old.joinable()) old.join();
+        }
+    }
     if (getenv("RSP_TIMING"))
         fprintf(stderr, "cholsol: schol %.2fs, chol (analysis + factor) %.2fs, solve (analysis + solve) %.2fs, free %.2fs\n", t1 - t0,
                 t2 - t1, t3 - t2, clock() - t3);
@@ -916,8 +1171,13 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
         devs = g_devices;
     }
     if (devs.size() <= 1 || nsys < 2 * (int64_t)devs.size()) {
-        if (devs.size() == 1 && hipSetDevice(devs[0]) != hipSuccess) return RSP_DEVICE_ERROR;
-        return cholsol_batch_on_device(A, Ax_all, B, nsys, order, status);
+        int before = -1;
+        if (devs.size() == 1) {
+            if (hipGetDevice(&before) != hipSuccess || hipSetDevice(devs[0]) != hipSuccess) return RSP_DEVICE_ERROR;
+        }
+        const int st = cholsol_batch_on_device(A, Ax_all, B, nsys, order, status);
+        if (before >= 0) (void)hipSetDevice(before);  // the caller's thread keeps the device it came with
+        return st;
     }
     // independent systems: contiguous shares, one host thread per device, no exchange between them (every device
     // repeats the ordering and the analysis for itself: they depend on the pattern alone and run side by side)
@@ -1030,9 +1290,12 @@ int rsp_lu_solve_dev_f64(rsp_lu *N, const rsp_symb *S, double *dB, int layout, i
         hipStream_t stream = (hipStream_t)stream_;
         const int64_t n = N->f.L.n;
         if (int st = lu_solvers(N)) return st;
-        if (!N->d_pinv.size()) {
-            N->d_pinv.upload(N->f.pinv);
-            if (S->s.has_q) N->d_q.upload(S->s.q.data(), (size_t)n);
+        if (!N->d_pinv.size()) N->d_pinv.upload(N->f.pinv);
+        // the column permutation comes with the call (as in rsp_lu_solve_f64): the device copy follows it
+        if (S->s.has_q && (N->q_host.size() != (size_t)n || !std::equal(N->q_host.begin(), N->q_host.end(), S->s.q.begin()))) {
+            RSP_HIP(hipDeviceSynchronize());  // (an earlier solve on another stream may still read the old copy)
+            N->q_host.assign(S->s.q.begin(), S->s.q.begin() + n);
+            N->d_q.upload(N->q_host.data(), (size_t)n);
         }
         N->guard.begin(stream);
         // x(pinv[k]) = b[k]  (ipvec, lib.rs:678), into a row-major workspace whatever the caller's layout

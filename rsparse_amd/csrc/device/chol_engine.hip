@@ -28,6 +28,8 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
     };
     n_ = A.n;
     annz_ = A.nnz();
+    factor_valid_ = false;
+    pattern_hash_ = pattern_hash(A);
     has_pinv_ = S.has_pinv;
     pinv_ = S.pinv;
     if (n_ >= INT32_MAX) return kBadInput;
@@ -496,8 +498,10 @@ int CholFactor::factorize(const CscView &A)
 {
     if (A.n != n_ || A.nnz() != annz_) return kBadInput;
     int32_t bad = INT_MAX;
+    factor_valid_ = false;
     factorize_values(A.x, 1, &bad);
-    return bad == INT_MAX ? kOk : kNotPositiveDefinite;
+    factor_valid_ = bad == INT_MAX;
+    return factor_valid_ ? kOk : kNotPositiveDefinite;
 }
 
 // nsys systems with the analysed pattern and the values Ax_all[s * nnz(A) ...]; first_bad[s] = smallest column of

@@ -37,6 +37,12 @@ class CholFactor {
     void factorize_values(const double *Ax_all, i64 nsys, int32_t *first_bad);
     void solve_batch(double *B, i64 nsys);
     i64 annz() const { return annz_; }
+    // waits for the host threads that analyse() left emitting the solve programmes (otherwise the first solve waits for them)
+    void finish_analysis() { join_pattern_jobs(); }
+    // false after a factorisation that failed (not positive definite): the values of L are unusable until one succeeds
+    bool valid() const { return factor_valid_; }
+    // hash of the analysed pattern of A (pattern_hash): a refactorisation must bring the same pattern
+    uint64_t pattern() const { return pattern_hash_; }
     void solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool permute, hipStream_t stream);
     void solve_host(double *B, i64 ldb, i64 nrhs);
     void download(i64 *Lp, i64 *Li, double *Lx) const;
@@ -57,7 +63,8 @@ class CholFactor {
     void build_solvers();
 
     i64 n_ = 0, lnz_ = 0, annz_ = 0;
-    bool has_pinv_ = false, single_use_ = false;
+    bool has_pinv_ = false, single_use_ = false, factor_valid_ = false;
+    uint64_t pattern_hash_ = 0;
     std::vector<i64> pinv_, Lp_, Li_;  // host copies (Li_ as the reference stores it)
     double flops_ = 0.0;
     double factor_ms_ = 0.0;

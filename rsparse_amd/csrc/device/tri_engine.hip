@@ -581,8 +581,13 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
     run_window(X, ld, nrhs, 0, nrhs, stream, nullptr);
 }
 
+static double *noalloc_scratch_for_current_device();
+
 void TriSolver::prepare_blocked(i64 total_cols)
 {
+    // (the allocation-free entry point only READS the address of its scratch array: looked up here, where allocating is allowed --
+    // the first lookup on a device may materialise the code object's globals)
+    (void)noalloc_scratch_for_current_device();
     if (!have_blocked_ && !have_sn_) {
         stage_supernodal();
         if (use_sn_) {

@@ -11,6 +11,37 @@
 
 namespace rsp {
 
+uint64_t pattern_hash(const CscView &A)
+{
+    auto mix = [](uint64_t z) {
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    // fixed chunks of 2^16 words, each hashed sequentially (position-dependent), chunk hashes combined in chunk order
+    auto hash_array = [&](const i64 *v, i64 count, uint64_t seed) {
+        constexpr i64 kChunk = 1 << 16;
+        const i64 nchunks = (count + kChunk - 1) / kChunk;
+        std::vector<uint64_t> part((size_t)nchunks, 0);
+        parallel_ranges(nchunks, 8, [&](i64 lo, i64 hi) {
+            for (i64 c = lo; c < hi; ++c) {
+                uint64_t h = seed + (uint64_t)c * 0x9e3779b97f4a7c15ull;
+                const i64 e = std::min(count, (c + 1) * kChunk);
+                for (i64 k = c * kChunk; k < e; ++k) h = (h ^ (uint64_t)v[k]) * 0x100000001b3ull + (h >> 29);
+                part[(size_t)c] = mix(h);
+            }
+        });
+        uint64_t h = seed;
+        for (uint64_t x : part) h = mix(h ^ x) + 0x9e3779b97f4a7c15ull;
+        return h;
+    };
+    uint64_t h = mix((uint64_t)A.m * 0x9e3779b97f4a7c15ull ^ (uint64_t)A.n);
+    h = hash_array(A.p, A.n + 1, h);
+    h = hash_array(A.i, A.p[A.n], h ^ 0x5851f42d4c957f2dull);
+    return h;
+}
+
+
 // The columns of T are cut into one contiguous piece of the VISITING order per host thread (ascending j for lsolve /
 // utsolve, descending for ltsolve / usolve -- the order in which the reference's loop meets the entries).  Thread k
 // counts its entries per unknown, the counts become (unknown, thread) offsets, and every thread then writes its entries

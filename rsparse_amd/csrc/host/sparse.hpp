@@ -83,6 +83,9 @@ std::vector<i64> fundamental_supernodes(const std::vector<i64> &parent, const st
 int sparse_lu(const CscView &A, const i64 *q, double tol, LuFactors &out);
 
 // ---- schedule.cpp -------------------------------------------------------------------------------
+// 64-bit hash of a matrix's PATTERN (m, n, p[0..n], i[0..nnz)): what an analysis depends on.  Computed on the host threads
+// (chunks hashed independently and combined in order: the value does not depend on the thread count).
+uint64_t pattern_hash(const CscView &A);
 // A triangular solve in "gather" form: unknown r is computed from earlier unknowns,
 //   x[r] = (b[r] - sum_p val[p] * x[idx[p]]) / diag[r],   p in [ptr[r], ptr[r+1])
 // processed in ascending r (lsolve, utsolve) or descending r (ltsolve, usolve).

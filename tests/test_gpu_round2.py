@@ -668,3 +668,157 @@ def test_qr_handle_solves_many():
         want = orc.qrsol(wide, c, 2)
         assert rel_inf(y, want) <= REL_X
         assert np.abs(to_dense(wide) @ y - c[:200]).max() <= 1e-9
+
+
+# ---- round 3: the analysis cache behind the one-shot cholsol (rsp_cholsol_f64) -------------------------------------------
+
+def _wait_cache_idle(limit_s=120.0):
+    import time
+    t0 = time.time()
+    while rs.cache_stats()["pending"] and time.time() - t0 < limit_s:
+        time.sleep(0.02)
+    assert rs.cache_stats()["pending"] == 0
+
+
+def test_cholsol_analysis_cache(monkeypatch):
+    """Same pattern, new values: a hit (refactorisation on the cached analysis) with the oracle's answer; one changed
+    index: a miss; RSP_ANALYSIS_CACHE=0: no cache at all; the entry budget evicts the least recently used pattern."""
+    _torch()
+    monkeypatch.setenv("RSP_ANALYSIS_CACHE", "2")
+    rs.cache_clear()
+    base = rs.cache_stats()
+    A = synth.laplacian_2d(90, 70)
+    n, p, i, x = A[0], A[2], A[3], A[4]
+    b = 2.0 * synth.splitmix64(11, n) - 1.0
+
+    def check(M, tag):
+        st, want = orc.cholsol(M, b.copy(), 0)
+        assert st == orc.OK
+        got = b.copy()
+        rs.cholsol(M, got, 0)
+        assert rel_inf(got, want) <= REL_X, tag
+
+    check(A, "first call")
+    s = rs.cache_stats()
+    assert s["misses"] == base["misses"] + 1 and s["hits"] == base["hits"]
+    _wait_cache_idle()
+    assert rs.cache_stats()["entries"] == 1
+    # values only: hits, each against the oracle's own cholsol of those values
+    for k in range(3):
+        xk = x.copy()
+        diag = np.flatnonzero(np.repeat(np.arange(n), np.diff(p)) == i)
+        xk[diag] += 0.25 * (k + 1)
+        check((A[0], A[1], p, i, xk), f"hit {k}")
+    s = rs.cache_stats()
+    assert s["hits"] == base["hits"] + 3 and s["misses"] == base["misses"] + 1
+    # a hit that is not positive definite reports it, and the next hit works again
+    xbad = x.copy()
+    xbad[np.flatnonzero(np.repeat(np.arange(n), np.diff(p)) == i)[n // 2]] = -4.0
+    with pytest.raises(rs.NotPositiveDefinite):
+        rs.cholsol((A[0], A[1], p, i, xbad), b.copy(), 0)
+    check(A, "hit after a failed hit")
+    # one changed index (an off-diagonal entry moved to a free slot of its column): another pattern, a miss
+    B = synth.laplacian_2d(90, 71)
+    before = rs.cache_stats()
+    bb = 2.0 * synth.splitmix64(12, B[0]) - 1.0
+    st, want = orc.cholsol(B, bb.copy(), 0)
+    got = bb.copy()
+    rs.cholsol(B, got, 0)
+    assert rel_inf(got, want) <= REL_X
+    assert rs.cache_stats()["misses"] == before["misses"] + 1
+    _wait_cache_idle()
+    # a third pattern: the budget of two entries evicts the least recently used one (A was used last before B)
+    Cm = synth.laplacian_2d(64, 64)
+    bc = 2.0 * synth.splitmix64(13, Cm[0]) - 1.0
+    rs.cholsol(Cm, bc.copy(), 0)
+    _wait_cache_idle()
+    s = rs.cache_stats()
+    assert s["entries"] == 2 and s["evicted"] >= base["evicted"] + 1
+    # another ordering of a cached pattern is another key
+    before = rs.cache_stats()
+    got = bc.copy()
+    rs.cholsol(Cm, got, -1)
+    st, want = orc.cholsol(Cm, bc.copy(), -1)
+    assert rel_inf(got, want) <= REL_X and rs.cache_stats()["misses"] == before["misses"] + 1
+    _wait_cache_idle()
+    # switched off: neither hits nor misses are counted, nothing is kept
+    rs.cache_clear()
+    monkeypatch.setenv("RSP_ANALYSIS_CACHE", "0")
+    before = rs.cache_stats()
+    check(A, "cache off")
+    check(A, "cache off, again")
+    s = rs.cache_stats()
+    assert s["entries"] == 0 and s["hits"] == before["hits"] and s["misses"] == before["misses"]
+
+
+def test_cholsol_analysis_cache_two_threads(monkeypatch):
+    """Two host threads calling cholsol with one pattern at once: an entry is out of the cache while a call uses it, so one
+    thread hits and the other takes the plain path; both get the oracle's answer."""
+    _torch()
+    import threading
+    monkeypatch.setenv("RSP_ANALYSIS_CACHE", "2")
+    rs.cache_clear()
+    A = synth.laplacian_2d(80, 80)
+    n = A[0]
+    b = 2.0 * synth.splitmix64(21, n) - 1.0
+    st, want = orc.cholsol(A, b.copy(), 0)
+    rs.cholsol(A, b.copy(), 0)
+    _wait_cache_idle()
+    out = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                g = b.copy()
+                rs.cholsol(A, g, 0)
+                out[k] = g
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
+    assert rel_inf(out[0], want) <= REL_X and rel_inf(out[1], want) <= REL_X
+    _wait_cache_idle()
+    rs.cache_clear()
+
+
+def test_handle_after_a_failed_refactorisation():
+    """A refactorisation that fails (not positive definite) leaves NO usable factor: solve, factor download and factor
+    view report NotPositiveDefinite until a refactorisation succeeds; values on another pattern of the same size are bad
+    input, not a silently wrong factor (round-2 advisor finding)."""
+    _torch()
+    A = synth.laplacian_2d(40, 30)
+    n, p, i, x = A[0], A[2], A[3], A[4]
+    F = rs.CholHandle(A, rs.schol(A, 0))
+    b = 2.0 * synth.splitmix64(31, n) - 1.0
+    st, want = orc.cholsol(A, b.copy(), 0)
+    X = b.copy()
+    F.solve(X)
+    assert rel_inf(X, want) <= REL_X
+    diag = np.flatnonzero(np.repeat(np.arange(n), np.diff(p)) == i)
+    xbad = x.copy()
+    xbad[diag[n // 3]] = -1.0
+    with pytest.raises(rs.NotPositiveDefinite):
+        F.refactor((A[0], A[1], p, i, xbad))
+    with pytest.raises(rs.NotPositiveDefinite):
+        F.solve(b.copy())
+    with pytest.raises(rs.NotPositiveDefinite):
+        F.factor()
+    # same size, another pattern: two row indices of one column swapped places with their neighbours' rows
+    i2 = i.copy()
+    c = n // 2
+    cols = np.repeat(np.arange(n), np.diff(p))
+    free = sorted(set(range(n)) - set(i[p[c]:p[c + 1]].tolist()))
+    off = [k for k in range(p[c], p[c + 1]) if i[k] != c][0]
+    i2[off] = free[0]
+    with pytest.raises(rs.DeviceError):
+        F.refactor((A[0], A[1], p, i2, x))
+    F.refactor(A)
+    X = b.copy()
+    F.solve(X)
+    assert rel_inf(X, want) <= REL_X
