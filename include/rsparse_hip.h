@@ -57,9 +57,13 @@ enum rsp_layout {
 const char *rsp_status_string(int status);
 int rsp_device_count(void);     /* number of visible HIP devices (0 if none) */
 int rsp_set_device(int device); /* device used by the calling thread's later calls */
-/* Devices that the entry points which shard INDEPENDENT work spread it over (now: rsp_cholsol_batch_f64, whose systems go
- * to the listed devices in contiguous shares, one host thread per device, no exchange between them).  n = 0 restores
- * the default (the calling thread's current device only); a device listed twice gets two shares.  Process-wide. */
+/* Devices that the entry points which shard INDEPENDENT work spread it over, in contiguous shares, one host thread per
+ * listed device, no exchange between them: the systems of rsp_cholsol_batch_f64, and the right-hand-side COLUMNS of the
+ * host-pointer solves rsp_chol_solve_f64 and rsp_tri_solve_f64 (from two columns per device).  For the solves every
+ * device but the handle's own works on a replica of the handle's resident solve programmes (and of pinv), copied device
+ * to device when first needed -- nothing is analysed twice, nothing visits the host -- and dropped by the next
+ * refactorisation.  The first listed device should be the handle's own.  n = 0 restores the default (the calling
+ * thread's current device only); a device listed twice gets two shares.  Process-wide. */
 int rsp_set_devices(const int *ids, int n);
 
 /* ---- one-shot triangular solves, x overwritten in place -------------------------------------

@@ -151,7 +151,8 @@ def device_count():
 
 
 def set_devices(ids):
-    """Devices that cholsol_batch spreads its systems over (empty list: the current device only)."""
+    """Devices that cholsol_batch spreads its systems over, and CholHandle.solve / TriHandle.solve their right-hand-side columns
+    (empty list: the current device only)."""
     a = np.ascontiguousarray(ids, np.int32)
     _check(lib().rsp_set_devices(a.ctypes.data if len(a) else None, len(a)))
 

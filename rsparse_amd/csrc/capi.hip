@@ -51,7 +51,17 @@ struct UseGuard {
 struct rsp_tri {
     TriSolver solver;
     UseGuard guard;
+    int device = -1;                                  // where the handle lives: the device current at its first solve
+    std::vector<std::unique_ptr<TriSolver>> replicas;  // rsp_set_devices: copies of the resident programme, by slot of the device list
 };
+// rsp_set_devices: the devices that entry points with independent work spread it over
+static std::mutex g_devices_guard;
+static std::vector<int> g_devices;
+static std::vector<int> listed_devices()
+{
+    std::lock_guard<std::mutex> lock(g_devices_guard);
+    return g_devices;
+}
 struct rsp_symb {
     Symbolic s;
 };
@@ -204,7 +214,59 @@ int rsp_tri_solve_f64(rsp_tri *h, double *X, int64_t ldx, int64_t nrhs)
     return guarded([&] {
         if (int st = require_device()) return st;
         std::lock_guard<std::mutex> lock(h->guard.m);
-        h->solver.solve_host(X, ldx, nrhs);  // synchronous: returns with the device idle
+        if (h->device < 0) RSP_HIP(hipGetDevice(&h->device));
+        const std::vector<int> devs = listed_devices();
+        const int64_t G = (int64_t)devs.size(), n = h->solver.n();
+        if (G <= 1 || nrhs < 2 * G || n == 0) {
+            h->solver.solve_host(X, ldx, nrhs);  // synchronous: returns with the device idle
+            return (int)RSP_OK;
+        }
+        // column blocks over the listed devices, one host thread per entry; every device but the handle's own works on a replica
+        // of the resident programme, copied device to device when first needed (TriSolver::clone_resident)
+        h->solver.prepare_blocked((nrhs + G - 1) / G);
+        RSP_HIP(hipDeviceSynchronize());
+        if ((int64_t)h->replicas.size() < G) h->replicas.resize((size_t)G);
+        std::vector<std::string> errors((size_t)G);
+        auto share = [&](int64_t g) {
+            try {
+                const int64_t lo = nrhs * g / G, hi = nrhs * (g + 1) / G, cols = hi - lo;
+                RSP_HIP(hipSetDevice(devs[(size_t)g]));
+                TriSolver *s = &h->solver;
+                if (!(g == 0 && devs[0] == h->device)) {
+                    std::unique_ptr<TriSolver> &R = h->replicas[(size_t)g];
+                    if (!R) {
+                        R.reset(new TriSolver);
+                        if (!h->solver.clone_resident(*R, h->device, devs[(size_t)g])) throw DeviceError("this handle's programme cannot be replicated");
+                        RSP_HIP(hipDeviceSynchronize());
+                    }
+                    s = R.get();
+                }
+                DeviceBuffer<double> d((size_t)n * (size_t)cols);
+                copy_block_to_device(d.get(), X + lo * ldx, n, ldx, cols);
+                hipStream_t stream = nullptr;
+                RSP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+                try {
+                    s->solve_device(d.get(), 0, n, cols, stream);
+                    RSP_HIP(hipStreamSynchronize(stream));
+                } catch (...) {
+                    (void)hipStreamDestroy(stream);
+                    throw;
+                }
+                (void)hipStreamDestroy(stream);
+                copy_block_to_host(X + lo * ldx, d.get(), n, ldx, cols);
+            } catch (const std::exception &e) {
+                errors[(size_t)g] = e.what()[0] ? e.what() : "error";
+            }
+        };
+        int before = 0;
+        RSP_HIP(hipGetDevice(&before));
+        std::vector<std::thread> pool;
+        for (int64_t g = 1; g < G; ++g) pool.emplace_back(share, g);
+        share(0);
+        for (std::thread &t : pool) t.join();
+        (void)hipSetDevice(before);
+        for (const std::string &e : errors)
+            if (!e.empty()) throw DeviceError("sharded solve: " + e);
         return (int)RSP_OK;
     });
 }
@@ -215,6 +277,7 @@ int rsp_tri_solve_dev_f64(rsp_tri *h, double *dX, int layout, int64_t ld, int64_
     if (layout == RSP_COL_MAJOR ? ld < h->solver.n() : ld < nrhs) return RSP_BAD_INPUT;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(h->guard.m);
+        if (h->device < 0) RSP_HIP(hipGetDevice(&h->device));
         h->guard.begin((hipStream_t)stream);
         h->solver.solve_device(dX, layout, ld, nrhs, (hipStream_t)stream);
         h->guard.end((hipStream_t)stream);
@@ -790,7 +853,9 @@ int rsp_chol_solve_f64(rsp_chol *F, double *B, int64_t ldb, int64_t nrhs)
     return guarded([&] {
         std::lock_guard<std::mutex> lock(F->guard.m);
         if (!F->f.valid()) return (int)RSP_NOT_POSITIVE_DEFINITE;  // the last (re)factorisation failed: nothing to solve with
-        F->f.solve_host(B, ldb, nrhs);
+        const std::vector<int> devs = listed_devices();
+        if (devs.size() > 1) F->f.solve_host_sharded(B, ldb, nrhs, devs);  // column blocks per device, replicas of the programmes
+        else F->f.solve_host(B, ldb, nrhs);
         return (int)RSP_OK;
     });
 }
@@ -1147,8 +1212,6 @@ static int cholsol_batch_on_device(const rsp_csc_f64 *A, const double *Ax_all, d
 
 
 // devices the multi-device entry points spread over (rsp_set_devices); empty = the calling thread's current device
-static std::mutex g_devices_guard;
-static std::vector<int> g_devices;
 
 int rsp_set_devices(const int *ids, int n)
 {
@@ -1166,10 +1229,7 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
     if (!sane_indices(A) || A->m != A->n || nsys < 0 || (nsys > 0 && (!Ax_all || !B))) return RSP_BAD_INPUT;
     if (nsys == 0 || A->n == 0) return RSP_OK;
     std::vector<int> devs;
-    {
-        std::lock_guard<std::mutex> lock(g_devices_guard);
-        devs = g_devices;
-    }
+    devs = listed_devices();
     if (devs.size() <= 1 || nsys < 2 * (int64_t)devs.size()) {
         int before = -1;
         if (devs.size() == 1) {

@@ -30,6 +30,8 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
     annz_ = A.nnz();
     factor_valid_ = false;
     pattern_hash_ = pattern_hash(A);
+    replicas_.clear();
+    (void)hipGetDevice(&device_);
     has_pinv_ = S.has_pinv;
     pinv_ = S.pinv;
     if (n_ >= INT32_MAX) return kBadInput;
@@ -499,6 +501,7 @@ int CholFactor::factorize(const CscView &A)
     if (A.n != n_ || A.nnz() != annz_) return kBadInput;
     int32_t bad = INT_MAX;
     factor_valid_ = false;
+    replicas_.clear();  // (copies of the solve programmes on other devices: made again from the new values when next needed)
     factorize_values(A.x, 1, &bad);
     factor_valid_ = bad == INT_MAX;
     return factor_valid_ ? kOk : kNotPositiveDefinite;
@@ -750,43 +753,120 @@ void CholFactor::build_solvers()
     upper_ = std::move(up);
 }
 
+// cholsol's solve phase on a device block: P (ipvec), lsolve, ltsolve, P' (pvec) -- lib.rs:383-386
+static void chol_solve_phase(TriSolver &lower, TriSolver &upper, const int64_t *d_pinv, DeviceBuffer<double> &work, i64 n, double *dB, int layout,
+                             i64 ld, i64 nrhs, hipStream_t stream)
+{
+    const int64_t *pinv = d_pinv;
+    const bool perm = pinv != nullptr;
+    const bool vector = (nrhs == 1 && (layout == 0 || ld == 1));
+    if (layout == 1 && !perm && !vector) {  // native layout, nothing to move
+        solve_pair_device(lower, upper, dB, ld, nrhs, stream);  // lsolve, ltsolve (lib.rs:384-385)
+        return;
+    }
+    if (vector && !perm) {  // a vector is its own n x 1 row-major block
+        solve_pair_device(lower, upper, dB, 1, 1, stream);
+        return;
+    }
+    work.resize((size_t)n * (size_t)((layout == 1 && !vector) ? ld : nrhs));
+    double *W = work.get();
+    const dim3 tgrid((unsigned)((n + 31) / 32), (unsigned)((nrhs + 31) / 32)), tblock(256);
+    const dim3 pgrid((unsigned)((n + 3) / 4)), pblock(256);
+    // x = P b : x[pinv[k]] = b[k]  (ipvec, lib.rs:383)
+    const dim3 vgrid((unsigned)((n + 255) / 256));
+    if (vector)
+        hipLaunchKernelGGL(dev::permute_vector, vgrid, dim3(256), 0, stream, dB, W, n, pinv, 1);
+    else if (layout == 0)
+        hipLaunchKernelGGL(dev::colmajor_to_rowmajor, tgrid, tblock, 0, stream, dB, ld, W, nrhs, n, (int)nrhs, pinv, 1);
+    else
+        hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, dB, W, ld, n, (int)nrhs, pinv, 1);
+    const i64 ldw = (layout == 0 || vector) ? nrhs : ld;
+    solve_pair_device(lower, upper, W, ldw, nrhs, stream);  // x = L \ x, x = L' \ x  (lib.rs:384-385)
+    // b = P' x : b[k] = x[pinv[k]]  (pvec, lib.rs:386)
+    if (vector)
+        hipLaunchKernelGGL(dev::permute_vector, vgrid, dim3(256), 0, stream, W, dB, n, pinv, 0);
+    else if (layout == 0)
+        hipLaunchKernelGGL(dev::rowmajor_to_colmajor, tgrid, tblock, 0, stream, W, nrhs, dB, ld, n, (int)nrhs, pinv, 0);
+    else
+        hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, W, dB, ld, n, (int)nrhs, pinv, 0);
+    RSP_HIP(hipGetLastError());
+}
+
 void CholFactor::solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool permute, hipStream_t stream)
 {
     if (nrhs <= 0 || n_ == 0) return;
     build_solvers();
-    const bool perm = permute && has_pinv_;
-    const int64_t *pinv = perm ? d_pinv.get() : nullptr;
-    const bool vector = (nrhs == 1 && (layout == 0 || ld == 1));
-    if (layout == 1 && !perm && !vector) {  // native layout, nothing to move
-        solve_pair_device(*lower_, *upper_, dB, ld, nrhs, stream);  // lsolve, ltsolve (lib.rs:384-385)
+    chol_solve_phase(*lower_, *upper_, (permute && has_pinv_) ? d_pinv.get() : nullptr, work_, n_, dB, layout, ld, nrhs, stream);
+}
+
+void CholFactor::solve_host_sharded(double *B, i64 ldb, i64 nrhs, const std::vector<int> &devices)
+{
+    const i64 G = (i64)devices.size();
+    if (nrhs <= 0 || n_ == 0) return;
+    if (G <= 1 || nrhs < 2 * G) {
+        solve_host(B, ldb, nrhs);
         return;
     }
-    if (vector && !perm) {  // a vector is its own n x 1 row-major block
-        solve_pair_device(*lower_, *upper_, dB, 1, 1, stream);
-        return;
-    }
-    work_.resize((size_t)n_ * (size_t)((layout == 1 && !vector) ? ld : nrhs));
-    double *W = work_.get();
-    const dim3 tgrid((unsigned)((n_ + 31) / 32), (unsigned)((nrhs + 31) / 32)), tblock(256);
-    const dim3 pgrid((unsigned)((n_ + 3) / 4)), pblock(256);
-    // x = P b : x[pinv[k]] = b[k]  (ipvec, lib.rs:383)
-    const dim3 vgrid((unsigned)((n_ + 255) / 256));
-    if (vector)
-        hipLaunchKernelGGL(dev::permute_vector, vgrid, dim3(256), 0, stream, dB, W, n_, pinv, 1);
-    else if (layout == 0)
-        hipLaunchKernelGGL(dev::colmajor_to_rowmajor, tgrid, tblock, 0, stream, dB, ld, W, nrhs, n_, (int)nrhs, pinv, 1);
-    else
-        hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, dB, W, ld, n_, (int)nrhs, pinv, 1);
-    const i64 ldw = (layout == 0 || vector) ? nrhs : ld;
-    solve_pair_device(*lower_, *upper_, W, ldw, nrhs, stream);  // x = L \ x, x = L' \ x  (lib.rs:384-385)
-    // b = P' x : b[k] = x[pinv[k]]  (pvec, lib.rs:386)
-    if (vector)
-        hipLaunchKernelGGL(dev::permute_vector, vgrid, dim3(256), 0, stream, W, dB, n_, pinv, 0);
-    else if (layout == 0)
-        hipLaunchKernelGGL(dev::rowmajor_to_colmajor, tgrid, tblock, 0, stream, W, nrhs, dB, ld, n_, (int)nrhs, pinv, 0);
-    else
-        hipLaunchKernelGGL(dev::permute_rows, pgrid, pblock, 0, stream, W, dB, ld, n_, (int)nrhs, pinv, 0);
-    RSP_HIP(hipGetLastError());
+    // the programmes must be resident and idle on this handle's device before anything is copied from them
+    build_solvers();
+    const i64 widest = (nrhs + G - 1) / G;
+    lower_->prepare_blocked(widest);
+    upper_->prepare_blocked(widest);
+    RSP_HIP(hipDeviceSynchronize());
+    if ((i64)replicas_.size() < G) replicas_.resize((size_t)G);
+    std::vector<std::string> errors((size_t)G);
+    auto share = [&](i64 g) {
+        try {
+            const i64 lo = nrhs * g / G, hi = nrhs * (g + 1) / G, cols = hi - lo;
+            if (cols == 0) return;
+            RSP_HIP(hipSetDevice(devices[(size_t)g]));
+            TriSolver *lo_s = lower_.get(), *up_s = upper_.get();
+            const int64_t *pinv = has_pinv_ ? d_pinv.get() : nullptr;
+            DeviceBuffer<double> *work = &work_;
+            if (!(g == 0 && devices[0] == device_)) {  // everyone but the handle's own device (first in the list) works on a replica
+                std::unique_ptr<Replica> &R = replicas_[(size_t)g];
+                if (!R || R->device != devices[(size_t)g]) {
+                    R.reset(new Replica);
+                    R->device = devices[(size_t)g];
+                    if (!lower_->clone_resident(R->lower, device_, R->device) || !upper_->clone_resident(R->upper, device_, R->device))
+                        throw DeviceError("this handle's solve programmes cannot be replicated (not the blocked programme)");
+                    if (has_pinv_) {
+                        R->pinv.resize(d_pinv.size());
+                        RSP_HIP(hipMemcpyPeer(R->pinv.get(), R->device, d_pinv.get(), device_, d_pinv.bytes()));
+                    }
+                    RSP_HIP(hipDeviceSynchronize());
+                }
+                lo_s = &R->lower;
+                up_s = &R->upper;
+                pinv = has_pinv_ ? R->pinv.get() : nullptr;
+                work = &R->work;
+            }
+            DeviceBuffer<double> d((size_t)n_ * (size_t)cols);
+            copy_block_to_device(d.get(), B + lo * ldb, n_, ldb, cols);
+            hipStream_t stream = nullptr;
+            RSP_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));  // shares of one device (a list that repeats it) run side by side
+            try {
+                chol_solve_phase(*lo_s, *up_s, pinv, *work, n_, d.get(), 0, n_, cols, stream);
+                RSP_HIP(hipStreamSynchronize(stream));
+            } catch (...) {
+                (void)hipStreamDestroy(stream);
+                throw;
+            }
+            (void)hipStreamDestroy(stream);
+            copy_block_to_host(B + lo * ldb, d.get(), n_, ldb, cols);
+        } catch (const std::exception &e) {
+            errors[(size_t)g] = e.what()[0] ? e.what() : "error";
+        }
+    };
+    int before = 0;
+    RSP_HIP(hipGetDevice(&before));
+    std::vector<std::thread> pool;
+    for (i64 g = 1; g < G; ++g) pool.emplace_back(share, g);
+    share(0);
+    for (std::thread &t : pool) t.join();
+    (void)hipSetDevice(before);
+    for (const std::string &e : errors)
+        if (!e.empty()) throw DeviceError("sharded solve: " + e);
 }
 
 void CholFactor::solve_host(double *B, i64 ldb, i64 nrhs)

@@ -45,6 +45,12 @@ class CholFactor {
     uint64_t pattern() const { return pattern_hash_; }
     void solve_device(double *dB, int layout, i64 ld, i64 nrhs, bool permute, hipStream_t stream);
     void solve_host(double *B, i64 ldb, i64 nrhs);
+    // The same with the columns of B shared out over `devices` (contiguous blocks, one host thread per entry; an id may be
+    // listed more than once): every other device works on a REPLICA of the resident solve programmes and of pinv, copied
+    // device to device when first needed (TriSolver::clone_resident) and dropped by the next refactorisation.  No
+    // exchange between the devices: the blocks are independent (north_star: right-hand-side blocks are sharded per GPU).
+    void solve_host_sharded(double *B, i64 ldb, i64 nrhs, const std::vector<int> &devices);
+    i64 replicas() const { return (i64)replicas_.size(); }
     void download(i64 *Lp, i64 *Li, double *Lx) const;
     void info(i64 *out) const;
     i64 n() const { return n_; }
@@ -110,6 +116,14 @@ class CholFactor {
 
     std::unique_ptr<TriSolver> lower_, upper_;
     DeviceBuffer<double> work_;
+    int device_ = 0;  // the device the handle lives on (current when it was analysed)
+    struct Replica {
+        int device = 0;
+        TriSolver lower, upper;
+        DeviceBuffer<i64> pinv;
+        DeviceBuffer<double> work;
+    };
+    std::vector<std::unique_ptr<Replica>> replicas_;  // by slot of the device list they were made for
     // single use: the pattern analysis of L for the two sweeps, started by analyze() on two host threads (no device
     // calls there); build_solvers() joins them and adds the values
     std::unique_ptr<TriSolver> pat_lower_, pat_upper_;

@@ -249,6 +249,12 @@ class TriSolver {
     // solve_device) and its scratch rows live in a file-scope __device__ array of kNoAllocScratchDoubles doubles.
     // Returns kBadInput when the programme is not resident or scratch_rows * nrhs exceeds the array.
     int solve_device_noalloc(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
+    // A REPLICA of this solver's resident blocked programme on another device (or again on the same one): every device
+    // array is copied device to device (hipMemcpyPeer), nothing is analysed or emitted again, nothing visits the host.
+    // The current device must be dst_device; this solver's programme must be resident (prepare_blocked) and idle.  The
+    // replica can solve and nothing else (no refresh: make a new one after a refactorisation).  false: the programme in
+    // use here is not the blocked one.
+    bool clone_resident(TriSolver &dst, int src_device, int dst_device) const;
 
    private:
     void build_program(i64 max_task_entries, TriProgram &P);

@@ -583,6 +583,45 @@ void TriSolver::run_blocked(double *X, i64 ld, i64 nrhs, hipStream_t stream)
 
 static double *noalloc_scratch_for_current_device();
 
+template <class T>
+static void clone_buffer(DeviceBuffer<T> &dst, const DeviceBuffer<T> &src, int src_device, int dst_device)
+{
+    dst.resize(src.size());
+    if (src.size()) RSP_HIP(hipMemcpyPeer(dst.get(), dst_device, src.get(), src_device, src.bytes()));
+}
+
+bool TriSolver::clone_resident(TriSolver &dst, int src_device, int dst_device) const
+{
+    if (!have_blocked_ || have_sn_ || blocked_.dense) return false;
+    dst.n_ = n_;
+    dst.nnz_ = nnz_;
+    dst.kind_ = kind_;
+    dst.num_row_levels_ = num_row_levels_;
+    const BlockedProgram &S = blocked_;
+    BlockedProgram &D = dst.blocked_;
+    D.ntasks = S.ntasks; D.nlevels = S.nlevels; D.nblocks = S.nblocks; D.scratch_rows = S.scratch_rows; D.big_chains = S.big_chains;
+    D.inverted_rows = S.inverted_rows; D.padded_entries = S.padded_entries; D.nclusters = S.nclusters; D.cluster_rows = S.cluster_rows;
+    D.cluster_entries = S.cluster_entries; D.launches = S.launches; D.cluster_slots = S.cluster_slots; D.nitems = S.nitems;
+    D.item_entries = S.item_entries; D.single_block_tasks = S.single_block_tasks; D.dense = false;
+    D.levels = S.levels;
+    clone_buffer(D.task_ptr, S.task_ptr, src_device, dst_device);
+    clone_buffer(D.hdr, S.hdr, src_device, dst_device);
+    clone_buffer(D.src_idx, S.src_idx, src_device, dst_device);
+    clone_buffer(D.coef, S.coef, src_device, dst_device);
+    clone_buffer(D.prologue, S.prologue, src_device, dst_device);
+    clone_buffer(D.items, S.items, src_device, dst_device);
+    clone_buffer(D.item_masks, S.item_masks, src_device, dst_device);
+    clone_buffer(D.clusters, S.clusters, src_device, dst_device);
+    clone_buffer(D.cluster_ids, S.cluster_ids, src_device, dst_device);
+    clone_buffer(D.groups, S.groups, src_device, dst_device);
+    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                4 * (std::min(D.cluster_slots, 64) * 512 + 1024)));  // (per device)
+    dst.have_blocked_ = true;
+    dst.sn_decided_ = true;
+    dst.use_sn_ = false;
+    return true;
+}
+
 void TriSolver::prepare_blocked(i64 total_cols)
 {
     // (the allocation-free entry point only READS the address of its scratch array: looked up here, where allocating is allowed --

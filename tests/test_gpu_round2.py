@@ -127,9 +127,8 @@ def test_full_size_c3_laplacian_3d_80():
     S = rs.schol(A, 0)
     F = rs.CholHandle(A, S)
     assert F.info()["lnz"] == 535760267  # an integer result: the same on every run and every machine
-    g = torch.Generator(device="cuda:0")
-    g.manual_seed(3)
-    B = torch.rand((n, k), dtype=torch.float64, device="cuda:0", generator=g) * 2.0 - 1.0
+    # X = 512 000 x 256, column-major, U(-1, 1) from SplitMix64 seed 3 (column c = the stream's c-th run of n doubles)
+    B = synth.splitmix64_torch(3, n * k, "cuda:0", -1.0, 1.0).reshape(k, n).T.contiguous()
     X = B.clone()
     st = torch.cuda.current_stream().cuda_stream
     F.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, k, k, True, st)
@@ -161,9 +160,9 @@ def test_full_size_c4_unsymmetric_200k():
     assert np.linalg.norm(Asp @ x - b) / np.linalg.norm(b) <= REL_RES
     S = rs.sqr(A, 1)
     N = rs.lu(A, S, 1.0)
-    g = torch.Generator(device="cuda:0")
-    g.manual_seed(4)
-    B = torch.rand((n, k), dtype=torch.float64, device="cuda:0", generator=g)
+    # b ~ U(0, 1) from SplitMix64 seed 5; the block's column c is the stream's c-th run of n doubles (column 0 = b)
+    B = synth.splitmix64_torch(5, n * k, "cuda:0").reshape(k, n).T.contiguous()
+    assert np.array_equal(B[:, 0].cpu().numpy(), b)
     X = B.clone()
     st = torch.cuda.current_stream().cuda_stream
     N.solve_dev(X.data_ptr(), rs.api.ROW_MAJOR, k, k, st)
@@ -608,6 +607,47 @@ def test_batch_sharded_over_devices():
             assert st.tolist() == st1.tolist() and np.array_equal(got, one)
         with pytest.raises(rs.DeviceError):
             rs.set_devices([0, 99])
+    finally:
+        rs.set_devices([])
+
+
+def test_rhs_blocks_sharded_over_devices():
+    """rsp_set_devices and the host-pointer solves (rsp_chol_solve_f64, rsp_tri_solve_f64): column blocks per listed device,
+    every device but the handle's own on a REPLICA of the resident programmes copied device to device (no second analysis).
+    On the one-GPU box device 0 is listed two and three times; the shares run the same programme on the same columns' data,
+    so the result equals the unsharded one bit for bit.  A refactorisation drops the replicas."""
+    _torch()
+    A = synth.laplacian_2d(90, 77)
+    n, k = A[0], 200
+    F = rs.CholHandle(A, rs.schol(A, 0))
+    B = np.asfortranarray((2.0 * synth.splitmix64(41, n * k) - 1.0).reshape(k, n).T)
+    want = B.copy(order="F")
+    F.solve(want)
+    st, w0 = orc.cholsol(A, B[:, 5].copy(), 0)
+    assert rel_inf(want[:, 5], w0) <= REL_X
+    st2, L = orc.chol(A, orc.schol(A, 0))
+    T = rs.TriHandle(L, 0)
+    tw = B.copy(order="F")
+    T.solve(tw)
+    try:
+        for devs in ([0, 0], [0, 0, 0]):
+            rs.set_devices(devs)
+            got = B.copy(order="F")
+            F.solve(got)
+            assert np.array_equal(got, want), devs
+            tg = B.copy(order="F")
+            T.solve(tg)
+            assert np.array_equal(tg, tw), devs
+        # new values: the replicas follow (they are made again from the refactorised programmes)
+        A2 = (A[0], A[1], A[2], A[3], A[4] * 1.5)
+        F.refactor(A2)
+        got = B.copy(order="F")
+        F.solve(got)
+        assert rel_inf(got, want / 1.5) <= 1e-12
+        # fewer columns than two per device: the plain path
+        small = B[:, :3].copy(order="F")
+        F.solve(small)
+        assert rel_inf(small, want[:, :3] / 1.5) <= 1e-12
     finally:
         rs.set_devices([])
 
