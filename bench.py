@@ -44,8 +44,8 @@ def bytes_trisolve(n, nnz, k):
 
 # what the triangular-solve kernels and their programmes are built from (the C ABI around them, the Cholesky and the host
 # factorisations are not: a change there does not move the solve's traffic)
-SOLVE_SOURCES = ("device/blocked_kernels.hip", "device/item_kernels.hip", "device/cluster_kernels.hip", "device/task_kernels.hip", "device/solve_kernels.hip",
-                 "device/dense_kernels.hip", "device/tri_engine.hip", "device/engine.hpp", "host/blocked.cpp", "host/schedule.cpp",
+SOLVE_SOURCES = ("device/blocked_kernels.hip", "device/item_kernels.hip", "device/cluster_kernels.hip", "device/solve_kernels.hip",
+                 "device/tri_engine.hip", "device/engine.hpp", "host/blocked.cpp", "host/schedule.cpp",
                  "host/sparse.hpp")
 
 

@@ -114,7 +114,8 @@ void rsp_tri_free(rsp_tri *h);
  * report[0..7] = bad indices, order violations, unknowns not written exactly once, levels, block tasks, clusters,
  *                unknowns inside clusters, kernel launches per sweep;  *max_rel_error = against sequential substitution.
  * task_blocks <= 0 and cluster_slots == 0 select the library defaults; cluster_slots > 0 builds group-record clusters of
- * that many LDS slots, cluster_slots < 0 dense matrix-core tasks of -cluster_slots slots (the bottom of the forest). */
+ * that many LDS slots (the bottom of the forest).  The programme is checked in both of its views: wide items as their
+ * twin 16-row blocks, and as items. */
 int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, int64_t *report,
                              double *max_rel_error);
 /* Host-only check of the REFILL of a programme (debug aid, no GPU): the programme of T is built, the values `new_values`
@@ -129,13 +130,6 @@ int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int 
  * emitted it. */
 int rsp_tri_program_checksum(const rsp_csc_f64 *T, int kind, int64_t task_blocks, int cluster_slots, uint64_t *out);
 
-/* The same for the SUPERNODAL programme (dense LDS tasks at the bottom of the forest, supernode products above; debug aid,
- * host only, no reference counterpart).  options (may be NULL) = {task slots (< 0: no tasks), widest node with folded
- * inverse, widest node, longest input list of one product}; 0 selects a default.
- * report[0..12] = bad indices, order violations, unknowns not written exactly once, levels, product items, tasks,
- *                 unknowns inside tasks, nodes, wide nodes, scratch rows, padded flops per right-hand side,
- *                 coefficient doubles, task steps. */
-int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *options, int64_t *report, double *max_rel_error);
 
 /* Host-only self-test of the threaded helpers the analyses use (host/parallel.hpp; debug aid, no reference counterpart,
  * no GPU): sorts `count` pseudo-random keys (seeded) with the threaded sort and fills an array over threaded ranges, on

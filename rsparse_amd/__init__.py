@@ -21,7 +21,6 @@ from .api import (  # noqa: F401
     program_checksum,
     validate_program,
     validate_refill,
-    validate_supernodal,
     cache_stats,
     cache_clear,
     amd,

@@ -71,7 +71,6 @@ def lib():
             "rsp_tri_validate_program": (cint, [csc, cint, i64, cint, vp, vp]),
             "rsp_tri_validate_refill": (cint, [csc, vp, cint, i64, cint, vp]),
             "rsp_tri_program_checksum": (cint, [csc, cint, i64, cint, vp]),
-            "rsp_tri_validate_supernodal": (cint, [csc, cint, vp, vp, vp]),
             "rsp_cache_stats": (cint, [vp]),
             "rsp_cache_clear": (cint, []),
             "rsp_selftest_host_threads": (cint, [i64, cint, C.c_uint64]),
@@ -569,20 +568,6 @@ def cache_stats():
 
 def cache_clear():
     _check(lib().rsp_cache_clear())
-
-
-def validate_supernodal(t, kind, task_slots=0, small_node=0, max_node=0, max_item_k=0):
-    """Host-only check of the supernodal programme built for `t` (rsp_tri_validate_supernodal); no GPU needed."""
-    t = _as_sprs(t)
-    opt = np.array([task_slots, small_node, max_node, max_item_k], np.int64)
-    rep = np.zeros(13, np.int64)
-    err = C.c_double(0.0)
-    _check(lib().rsp_tri_validate_supernodal(C.byref(t._view()), kind, opt.ctypes.data, rep.ctypes.data, C.byref(err)))
-    keys = ("bad_index", "order_violations", "unwritten", "levels", "items", "tasks", "task_rows", "nodes", "big_nodes",
-            "scratch_rows", "padded_flops_per_col", "coef_doubles", "task_steps")
-    d = dict(zip(keys, rep.tolist()))
-    d["max_rel_error"] = err.value
-    return d
 
 
 def solve_pair_dev(first, second, ptr, ld, nrhs, stream=None):

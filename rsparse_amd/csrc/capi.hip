@@ -322,17 +322,6 @@ int rsp_tri_info(const rsp_tri *h, int64_t *info)
     info[2] = s.num_row_levels();
     const BlockedProgram &Bp = s.blocked_program();
     const bool blocked = Bp.nblocks > 0;  // the programme the multi-rhs path actually ran
-    if (s.uses_supernodal() && s.supernodal_program().nlevels > 0) {  // the supernodal programme ran
-        const SupernodalProgram &Sp = s.supernodal_program();
-        info[3] = Sp.nitems + Sp.ntasks;
-        info[4] = Sp.launches;
-        info[5] = (int64_t)Sp.device_bytes();
-        info[6] = s.algorithmic_bytes(1);
-        info[7] = 0;
-        info[8] = Sp.scratch_rows;
-        info[9] = info[10] = 0;
-        return RSP_OK;
-    }
     info[3] = blocked ? Bp.ntasks : P.ntasks;
     info[4] = blocked ? Bp.launches : P.nlevels;
     info[5] = (int64_t)(blocked ? Bp.device_bytes() : P.device_bytes());
@@ -392,10 +381,8 @@ int rsp_tri_validate_program(const rsp_csc_f64 *T, int kind, int64_t task_blocks
     return guarded([&] {
         GatherForm G;
         if (int st = build_gather_form(view_of(T), kind, G)) return st;
-        // cluster_slots > 0: group-record clusters of that many slots; < 0: dense tasks of -cluster_slots slots; 0: the default
-        const bool dense = cluster_slots < 0 || (cluster_slots == 0 && kDenseTasks != 0);
-        const int slots = cluster_slots > 0 ? cluster_slots : cluster_slots < 0 ? -cluster_slots : (dense ? kDenseSlots : kClusterSlots);
-        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, slots, dense);
+        const int slots = cluster_slots > 0 ? cluster_slots : kClusterSlots;
+        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, slots);
         // both views of the programme: the wide items as their twin blocks, and as items
         ProgramReport R = check_block_program(G, P, false);
         if (!P.items.empty()) {
@@ -428,7 +415,7 @@ int rsp_tri_program_checksum(const rsp_csc_f64 *T, int kind, int64_t task_blocks
         GatherForm G;
         G.keep_src = true;
         if (int st = build_gather_form(view_of(T), kind, G)) return st;
-        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, cluster_slots > 0 ? cluster_slots : kClusterSlots, false);
+        const BlockProgram P = build_block_program(G, task_blocks > 0 ? task_blocks : kTaskBlocks, cluster_slots > 0 ? cluster_slots : kClusterSlots);
         auto fnv = [](const void *data, size_t bytes) {
             uint64_t h = 1469598103934665603ull;
             const unsigned char *p = static_cast<const unsigned char *>(data);
@@ -456,7 +443,7 @@ int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int 
         GatherForm G;
         G.keep_src = true;
         if (int st = build_gather_form(view_of(T), kind, G)) return st;
-        BlockProgram P = build_block_program(G, blocks, slots, false);
+        BlockProgram P = build_block_program(G, blocks, slots);
         CscView T2 = view_of(T);
         T2.x = new_values;
         report[0] = P.refill.valid ? 1 : 0;
@@ -467,7 +454,7 @@ int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int 
         if (!refill_block_program(G, P)) return (int)RSP_INTERNAL_ERROR;
         GatherForm G2;
         if (int st = build_gather_form(T2, kind, G2)) return st;
-        const BlockProgram Q = build_block_program(G2, blocks, slots, false);
+        const BlockProgram Q = build_block_program(G2, blocks, slots);
         if (Q.coef.size() != P.coef.size() || Q.groups.size() != P.groups.size()) return (int)RSP_INTERNAL_ERROR;
         auto same = [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; };
         for (size_t e = 0; e < P.coef.size(); ++e) report[1] += !same(P.coef[e], Q.coef[e]);
@@ -476,43 +463,6 @@ int rsp_tri_validate_refill(const rsp_csc_f64 *T, const double *new_values, int 
             for (int e = 0; e < 4; ++e) ok = ok && same(P.groups[g].coef[e], Q.groups[g].coef[e]);
             report[2] += !ok;
         }
-        return (int)RSP_OK;
-    });
-}
-
-int rsp_tri_validate_supernodal(const rsp_csc_f64 *T, int kind, const int64_t *options, int64_t *report, double *max_rel_error)
-{
-    if (!sane(T) || kind < 0 || kind > 3 || !report || !max_rel_error) return RSP_BAD_INPUT;
-    return guarded([&] {
-        GatherForm G, C;
-        if (int st = build_gather_form(view_of(T), kind, G)) return st;
-        const bool scatter = kind == RSP_LSOLVE || kind == RSP_USOLVE;
-        if (scatter)
-            if (int st = build_gather_form(view_of(T), kind ^ 1, C)) return st;
-        SnOptions opt;
-        if (options) {
-            if (options[0] > 0) opt.task_slots = (int)std::min<int64_t>(options[0], 319);
-            if (options[0] < 0) opt.task_slots = 0;  // no tasks at all
-            if (options[1] > 0) opt.small_node = options[1];
-            if (options[2] > 0) opt.max_node = options[2];
-            if (options[3] > 0) opt.max_item_k = options[3];
-        }
-        const SnProgram P = build_supernodal_program(G, scatter ? &C : nullptr, scatter, opt);
-        const ProgramReport R = check_supernodal_program(G, P);
-        report[0] = R.bad_index;
-        report[1] = R.order_violations;
-        report[2] = R.unwritten;
-        report[3] = (int64_t)P.item_level_ptr.size() - 1;
-        report[4] = (int64_t)P.items.size();
-        report[5] = (int64_t)P.tasks.size();
-        report[6] = P.task_rows;
-        report[7] = P.nnodes;
-        report[8] = P.big_nodes;
-        report[9] = P.scratch_rows;
-        report[10] = P.padded_flops_per_col;
-        report[11] = (int64_t)(P.coef.size() + 2 * P.task_recs.size());
-        report[12] = (int64_t)P.task_recs.size() / 4;
-        *max_rel_error = R.max_rel_error;
         return (int)RSP_OK;
     });
 }

@@ -129,10 +129,6 @@ struct BlockedProgram {
     DeviceBuffer<ClusterHeader> clusters;
     DeviceBuffer<int32_t> cluster_ids;
     DeviceBuffer<GroupRec> groups;
-    bool dense = false;  // the clusters are dense tasks (dense_kernels.hip)
-    DeviceBuffer<uint32_t> dense_steps;
-    DeviceBuffer<double> dense_coef;
-    i64 dense_nodes = 0, dense_ksteps = 0;
     struct Level {
         i64 task_begin[BlockProgram::kClasses];  // by class (BlockProgram::level_class_ptr)
         int ntasks[BlockProgram::kClasses];
@@ -147,34 +143,9 @@ struct BlockedProgram {
     size_t device_bytes() const
     {
         return task_ptr.bytes() + hdr.bytes() + prologue.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
-               groups.bytes() + dense_steps.bytes() + dense_coef.bytes() + items.bytes() + item_masks.bytes();
+               groups.bytes() + items.bytes() + item_masks.bytes();
     }
 };
-
-// The supernodal multi-right-hand-side programme (host/supernodal.cpp) resident on the device.
-struct SupernodalProgram {
-    i64 nitems = 0, ntasks = 0, nlevels = 0, launches = 0, scratch_rows = 0, nnodes = 0, big_nodes = 0, task_rows = 0, padded_flops_per_col = 0;
-    int task_slots = 0;
-    DeviceBuffer<SnItem> items;
-    DeviceBuffer<int32_t> ids;
-    DeviceBuffer<double> coef;
-    DeviceBuffer<ClusterHeader> tasks;
-    DeviceBuffer<int32_t> task_ids;
-    DeviceBuffer<SnTaskRec> task_recs;
-    struct Level {
-        i64 item_begin, task_begin;
-        int nitems, ntasks;
-        int n4, n2, n1;  // items by the number of wavefronts that share them (sorted that way inside the level)
-    };
-    std::vector<Level> levels;
-    size_t device_bytes() const
-    {
-        return items.bytes() + ids.bytes() + coef.bytes() + tasks.bytes() + task_ids.bytes() + task_recs.bytes();
-    }
-};
-
-// slot / node-end words of the dense-task kernel from the host programme's slots and meta arrays
-std::vector<uint32_t> pack_dense_steps(const std::vector<uint16_t> &slots, const std::vector<int32_t> &meta);
 
 // Analyse-once / solve-many engine for one triangular factor and one of the four solve kinds.
 class TriSolver {
@@ -196,13 +167,10 @@ class TriSolver {
     const TriProgram &multi_program() const { return multi_; }
     const TriProgram &single_program() const { return single_; }
     const BlockedProgram &blocked_program() const { return blocked_; }
-    const SupernodalProgram &supernodal_program() const { return sn_; }
-    bool uses_supernodal() const { return use_sn_; }
     // kernel launches per sweep and tasks of the programme that has actually been built (zeros before the first solve)
     void summary(i64 &launches, i64 &tasks) const
     {
-        if (have_sn_) { launches = sn_.launches; tasks = sn_.nitems + sn_.ntasks; }
-        else if (have_blocked_) { launches = blocked_.launches; tasks = blocked_.ntasks; }
+        if (have_blocked_) { launches = blocked_.launches; tasks = blocked_.ntasks; }
         else if (have_single_) { launches = single_.nlevels; tasks = single_.ntasks; }
         else if (have_multi_) { launches = multi_.nlevels; tasks = multi_.ntasks; }
         else { launches = 0; tasks = 0; }
@@ -235,7 +203,7 @@ class TriSolver {
     // PROGRAMME AHEAD OF THE VALUES: after a pattern-only analyze() (keep_for_refill() on), emit the blocked programme with
     // placeholder values -- host work, any thread, e.g. beside a numeric factorisation that is still running.  Every
     // value in it is rewritten by refresh_device() before the first solve; adopt_staged() uploads it (false: nothing
-    // usable was staged, e.g. the supernodal engine is selected).
+    // usable was staged).
     void stage_blocked_pattern();
     bool adopt_staged();
     // sends the recipe to the device ahead of the first refresh_device (which would do it otherwise); T: the pattern
@@ -263,11 +231,6 @@ class TriSolver {
     void run_blocked(double *X_rowmajor, i64 ld, i64 nrhs, hipStream_t stream);
     void build_blocked();
     void run_single(double *x, hipStream_t stream);
-    // supernodal programme: staged on the host (and accepted or not) before the blocked one would be built
-    void stage_supernodal();
-    void build_supernodal();
-    void run_window_supernodal(double *X_rowmajor, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
-                               double *scratch_base);
 
     i64 n_ = 0, nnz_ = 0, num_row_levels_ = 0;
     int kind_ = 0;
@@ -276,9 +239,6 @@ class TriSolver {
     TriProgram multi_, single_;
     BlockedProgram blocked_;
     bool have_multi_ = false, have_single_ = false, have_blocked_ = false, single_use_levels_ = false;
-    SupernodalProgram sn_;
-    bool sn_decided_ = false, use_sn_ = false, have_sn_ = false;
-    std::unique_ptr<SnProgram> staged_sn_;
     std::unique_ptr<BlockProgram> staged_;
     std::unique_ptr<BlockProgram> kept_;  // keep_for_refill(): coef, groups and the recipe of the resident programme
     struct DeviceRecipe {
@@ -312,10 +272,6 @@ constexpr i64 kLeanLaunchWorkgroups = 128;  // levels with at least this many 51
 constexpr i64 kPairParts = 2;  // column parts of the pair pipeline (C2, 256 right-hand sides: 3 parts are 2 % faster but re-read the
                                // coefficients once more -- 35 instead of 25 GB of fabric traffic per step; 4 parts lose)
 constexpr i64 kLeanLaunchWorkgroupsSingle = 128;  // the same switch for a single right-hand side (deep-fetch gather)
-constexpr i64 kSupernodal = 0;    // multi-right-hand-side programme: 0 blocked, 1 supernodal, 2 supernodal when it needs at most kSupernodalMaxLaunches
-constexpr i64 kSupernodalMaxLaunches = 300;
-constexpr i64 kDenseTasks = 0;   // 1: the bottom of the forest runs as dense LDS tasks (dense_kernels.hip), 0: as group-record clusters
-constexpr i64 kDenseNT = 1;      // 16-column tiles per wavefront of a dense task
 constexpr i64 kNoAllocScratchDoubles = 4 << 20;  // 32 MiB per GPU, held until the process ends (rsp_tri_solve_dev_noalloc_f64)
 constexpr i64 kItemLaunchWaves = 512;  // a level runs its wide items as items (dev::solve_items) from this many (item, 64 columns) pairs,
                                        // as their twin 16-row blocks below it

@@ -13,9 +13,6 @@
 #include "blocked_kernels.hip"
 #include "item_kernels.hip"
 #include "cluster_kernels.hip"
-#include "dense_kernels.hip"
-#include "sn_kernels.hip"
-#include "task_kernels.hip"
 #include "refill_kernels.hip"
 
 namespace rsp {
@@ -140,159 +137,11 @@ static i64 env_or(const char *name, i64 fallback)
     return v && *v ? atol(v) : fallback;
 }
 
-std::vector<uint32_t> pack_dense_steps(const std::vector<uint16_t> &slots, const std::vector<int32_t> &meta)
-{
-    std::vector<uint32_t> steps(slots.size() + 64, 0);  // the kernel prefetches with clamped step numbers; slack for safety
-    for (size_t k = 0; k < meta.size(); ++k) {
-        const uint32_t rows = meta[k] < 0 ? ((uint32_t)meta[k] >> 20) & 31u : 0u;
-        for (int g = 0; g < 4; ++g) steps[4 * k + g] = (uint32_t)slots[4 * k + g] | (rows << 16);
-    }
-    return steps;
-}
-
-// the dual of a gather form: who READS every unknown (entries (r <- s, v) turned into (s -> r, v)), processed the other way
-static GatherForm dual_gather_form(const GatherForm &G)
-{
-    GatherForm C;
-    C.n = G.n;
-    C.descending = !G.descending;
-    C.diag = G.diag;
-    C.ptr.assign(G.n + 1, 0);
-    for (int32_t s : G.idx) C.ptr[s + 1]++;
-    for (i64 r = 0; r < G.n; ++r) C.ptr[r + 1] += C.ptr[r];
-    C.idx.resize(G.idx.size());
-    C.val.resize(G.val.size());
-    std::vector<i64> fill(C.ptr.begin(), C.ptr.end() - 1);
-    for (i64 r = 0; r < G.n; ++r)
-        for (i64 p = G.ptr[r]; p < G.ptr[r + 1]; ++p) {
-            const i64 q = fill[G.idx[p]]++;
-            C.idx[q] = (int32_t)r;
-            C.val[q] = G.val[p];
-        }
-    return C;
-}
-
-// host half of the supernodal programme; decides whether this factor takes it (few enough launches) or the blocked one
-void TriSolver::stage_supernodal()
-{
-    if (sn_decided_) return;
-    sn_decided_ = true;
-    const i64 mode = env_or("RSP_SUPERNODAL", kSupernodal);
-    if (mode == 0 || n_ == 0) return;
-    const double t0 = now_s();
-    const bool scatter = kind_ == 0 || kind_ == 2;
-    SnOptions opt;
-    opt.task_slots = (int)std::min<i64>(env_or("RSP_SN_TASK_SLOTS", opt.task_slots), 319);  // the task kernel keeps one id per 8 slots in 40 registers
-    opt.small_node = env_or("RSP_SN_SMALL_NODE", opt.small_node);
-    opt.max_node = env_or("RSP_SN_MAX_NODE", opt.max_node);
-    opt.max_item_k = env_or("RSP_SN_MAX_ITEM_K", opt.max_item_k);
-    std::unique_ptr<SnProgram> P;
-    if (scatter) {
-        const GatherForm C = dual_gather_form(G_);
-        P.reset(new SnProgram(build_supernodal_program(G_, &C, true, opt)));
-    } else {
-        P.reset(new SnProgram(build_supernodal_program(G_, nullptr, false, opt)));
-    }
-    i64 launches = 0;
-    for (size_t l = 0; l + 1 < P->item_level_ptr.size(); ++l)
-        launches += (P->item_level_ptr[l + 1] > P->item_level_ptr[l]) + (P->task_level_ptr[l + 1] > P->task_level_ptr[l]);
-    use_sn_ = mode == 1 || launches <= env_or("RSP_SN_MAX_LAUNCHES", kSupernodalMaxLaunches);
-    if (getenv("RSP_TIMING"))
-        fprintf(stderr, "supernodal programme: %.2fs, %lld launches, %zu items, %zu tasks, %lld nodes -> %s\n", now_s() - t0, (long long)launches,
-                P->items.size(), P->tasks.size(), (long long)P->nnodes, use_sn_ ? "taken" : "not taken");
-    if (use_sn_) staged_sn_ = std::move(P);
-}
-
-void TriSolver::build_supernodal()
-{
-    SnProgram P = std::move(*staged_sn_);
-    staged_sn_.reset();
-    SupernodalProgram &D = sn_;
-    D.nitems = (i64)P.items.size();
-    D.ntasks = (i64)P.tasks.size();
-    D.nlevels = (i64)P.item_level_ptr.size() - 1;
-    D.scratch_rows = P.scratch_rows;
-    D.nnodes = P.nnodes;
-    D.big_nodes = P.big_nodes;
-    D.task_rows = P.task_rows;
-    D.padded_flops_per_col = P.padded_flops_per_col;
-    D.task_slots = P.task_slots_max;
-    D.levels.clear();
-    D.launches = 0;
-    for (i64 l = 0; l < D.nlevels; ++l) {
-        SupernodalProgram::Level lv{P.item_level_ptr[l], P.task_level_ptr[l], (int)(P.item_level_ptr[l + 1] - P.item_level_ptr[l]),
-                                    (int)(P.task_level_ptr[l + 1] - P.task_level_ptr[l]), 0, 0, 0};
-        for (i64 k = P.item_level_ptr[l]; k < P.item_level_ptr[l + 1]; ++k) {
-            const int ns = P.items[k].nsplit;
-            (ns == 4 ? lv.n4 : ns == 2 ? lv.n2 : lv.n1)++;
-        }
-        D.launches += (lv.nitems > 0) + (lv.ntasks > 0);
-        D.levels.push_back(lv);
-    }
-    D.items.upload(P.items);
-    D.ids.upload(P.ids);
-    D.coef.upload(P.coef);
-    D.tasks.upload(P.tasks);
-    D.task_ids.upload(P.task_ids);
-    D.task_recs.upload(P.task_recs);
-    const int lds_bytes = (D.task_slots + 1) * 128;
-    if (lds_bytes > 64 * 1024) throw DeviceError("tasks do not fit in LDS");
-    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_sparse_tasks<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_sparse_tasks<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-}
-
-void TriSolver::run_window_supernodal(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_cols, hipStream_t stream, hipEvent_t after_heavy,
-                                      double *scratch_base)
-{
-    const SupernodalProgram &P = sn_;
-    double *const Sw = scratch_base + col_off;
-    const i64 lds = total_cols;
-    const int nchunks = (int)((nrhs + 63) / 64);
-    const bool fast = nrhs % 4 == 0 && ld % 2 == 0 && lds % 2 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Sw % 16) == 0;
-    const int dchunks = (int)((nrhs + 15) / 16);
-    const bool dfast = fast && nrhs % 16 == 0;
-    const dev::TaskArrays DA{P.tasks.get(), P.task_ids.get(), P.task_recs.get()};
-    const dev::SnArrays SA{P.items.get(), P.ids.get(), P.coef.get()};
-    const size_t lds_bytes = (size_t)(P.task_slots + 1) * 128;
-    auto task_kernel = dfast ? dev::solve_sparse_tasks<true> : dev::solve_sparse_tasks<false>;
-    auto item_kernel = fast ? dev::sn_gemm<true> : dev::sn_gemm<false>;
-    i64 total = 0, done = 0;
-    if (after_heavy)
-        for (const auto &lv : P.levels) total += (i64)lv.ntasks * nchunks + (i64)lv.nitems * nchunks;
-    bool recorded = false;
-    for (const auto &lv : P.levels) {
-        if (after_heavy && !recorded && done * 10 >= total * 9) {
-            RSP_HIP(hipEventRecord(after_heavy, stream));
-            recorded = true;
-        }
-        if (lv.ntasks) {
-            const i64 wgs = ((i64)lv.ntasks * dchunks + 7) / 8 * 8;
-            hipLaunchKernelGGL(task_kernel, dim3((unsigned)wgs), dim3(64), lds_bytes, stream, DA, lv.task_begin, lv.ntasks, dchunks, X, ld, Sw, lds,
-                               (int)nrhs);
-        }
-        if (lv.nitems) {
-            const i64 works = (i64)lv.n4 * nchunks + ((i64)lv.n2 * nchunks + 1) / 2 + ((i64)lv.n1 * nchunks + 3) / 4;
-            const i64 wgs = (works + 7) / 8 * 8;
-            const dev::SnLevel SL{lv.item_begin, lv.n4, lv.n2, lv.n1};
-            hipLaunchKernelGGL(item_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, SA, SL, nchunks, X, ld, Sw, lds, (int)nrhs);
-        }
-        done += (i64)lv.ntasks * nchunks + (i64)lv.nitems * nchunks;
-    }
-    if (after_heavy && !recorded) RSP_HIP(hipEventRecord(after_heavy, stream));
-    RSP_HIP(hipGetLastError());
-}
-
 // host half of build_blocked(): no device call, so two solvers can be staged on two host threads
 void TriSolver::stage_blocked()
 {
     if (host_values_stale_) throw DeviceError("the programme needs the factor's values on the host: refreshed on the device only");
-    stage_supernodal();
-    if (use_sn_) return;
-    const bool dense = env_or("RSP_DENSE_TASKS", kDenseTasks) != 0;
-    // a dense task's rows must fit the LDS share of a wavefront: four wavefronts per CU, 128 bytes per slot and column tile
-    const i64 nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
-    const i64 slots = dense ? std::min<i64>(env_or("RSP_DENSE_SLOTS", kDenseSlots / nt), 1200 / nt) : env_or("RSP_CLUSTER_SLOTS", kClusterSlots);
-    staged_.reset(new BlockProgram(build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)slots, dense)));
+    staged_.reset(new BlockProgram(build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots))));
 }
 
 void TriSolver::set_single_use()
@@ -402,25 +251,6 @@ void TriSolver::build_blocked()
     D.clusters.upload(P.clusters);
     D.cluster_ids.upload(P.cluster_ids);
     D.groups.upload(P.groups);
-    D.dense = P.dense;
-    D.dense_nodes = P.dense_nodes;
-    D.dense_ksteps = (i64)P.dense_meta.size();
-    if (P.dense) {
-        // the kernel prefetches whole quads of k-steps with clamped indices: never past these ends
-        D.dense_steps.upload(pack_dense_steps(P.dense_slots, P.dense_meta));
-        P.dense_coef.resize(P.dense_coef.size() + 64, 0.0);
-        D.dense_coef.upload(P.dense_coef);
-        auto allow = [&](const void *f, int nt) {
-            const int bytes = (D.cluster_slots + 1) * 128 * nt;
-            if (bytes <= 160 * 1024) RSP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        };
-        allow((const void *)dev::solve_dense_tasks<1, true>, 1);
-        allow((const void *)dev::solve_dense_tasks<1, false>, 1);
-        allow((const void *)dev::solve_dense_tasks<2, true>, 2);
-        allow((const void *)dev::solve_dense_tasks<2, false>, 2);
-        allow((const void *)dev::solve_dense_tasks<4, true>, 4);
-        allow((const void *)dev::solve_dense_tasks<4, false>, 4);
-    }
     RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * (std::min(D.cluster_slots, 64) * 512 + 1024)));
     if (getenv("RSP_TIMING")) fprintf(stderr, "tri programme: build %.2fs, upload %.2fs\n", tb1 - tb0, now_s() - tb1);
@@ -435,10 +265,8 @@ void TriSolver::build_blocked()
 
 void TriSolver::stage_blocked_pattern()
 {
-    if (G_.src.empty() || env_or("RSP_SUPERNODAL", kSupernodal) != 0 || env_or("RSP_DENSE_TASKS", kDenseTasks) != 0) return;
-    sn_decided_ = true;  // (the blocked engine: the supernodal one is off)
-    use_sn_ = false;
-    staged_.reset(new BlockProgram(build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots), false)));
+    if (G_.src.empty()) return;
+    staged_.reset(new BlockProgram(build_block_program(G_, env_or("RSP_TASK_BLOCKS", kTaskBlocks), (int)env_or("RSP_CLUSTER_SLOTS", kClusterSlots))));
     if (!staged_->refill.valid) staged_.reset();
     host_values_stale_ = true;  // the gather form holds no values at all yet
 }
@@ -446,7 +274,7 @@ void TriSolver::stage_blocked_pattern()
 bool TriSolver::adopt_staged()
 {
     if (have_blocked_) return kept_ != nullptr;  // already uploaded
-    if (!staged_ || have_sn_) return false;
+    if (!staged_) return false;
     build_blocked();
     have_blocked_ = true;
     return kept_ != nullptr;
@@ -592,7 +420,7 @@ static void clone_buffer(DeviceBuffer<T> &dst, const DeviceBuffer<T> &src, int s
 
 bool TriSolver::clone_resident(TriSolver &dst, int src_device, int dst_device) const
 {
-    if (!have_blocked_ || have_sn_ || blocked_.dense) return false;
+    if (!have_blocked_) return false;
     dst.n_ = n_;
     dst.nnz_ = nnz_;
     dst.kind_ = kind_;
@@ -602,7 +430,7 @@ bool TriSolver::clone_resident(TriSolver &dst, int src_device, int dst_device) c
     D.ntasks = S.ntasks; D.nlevels = S.nlevels; D.nblocks = S.nblocks; D.scratch_rows = S.scratch_rows; D.big_chains = S.big_chains;
     D.inverted_rows = S.inverted_rows; D.padded_entries = S.padded_entries; D.nclusters = S.nclusters; D.cluster_rows = S.cluster_rows;
     D.cluster_entries = S.cluster_entries; D.launches = S.launches; D.cluster_slots = S.cluster_slots; D.nitems = S.nitems;
-    D.item_entries = S.item_entries; D.single_block_tasks = S.single_block_tasks; D.dense = false;
+    D.item_entries = S.item_entries; D.single_block_tasks = S.single_block_tasks;
     D.levels = S.levels;
     clone_buffer(D.task_ptr, S.task_ptr, src_device, dst_device);
     clone_buffer(D.hdr, S.hdr, src_device, dst_device);
@@ -617,8 +445,6 @@ bool TriSolver::clone_resident(TriSolver &dst, int src_device, int dst_device) c
     RSP_HIP(hipFuncSetAttribute((const void *)dev::solve_clusters, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 4 * (std::min(D.cluster_slots, 64) * 512 + 1024)));  // (per device)
     dst.have_blocked_ = true;
-    dst.sn_decided_ = true;
-    dst.use_sn_ = false;
     return true;
 }
 
@@ -627,23 +453,14 @@ void TriSolver::prepare_blocked(i64 total_cols)
     // (the allocation-free entry point only READS the address of its scratch array: looked up here, where allocating is allowed --
     // the first lookup on a device may materialise the code object's globals)
     (void)noalloc_scratch_for_current_device();
-    if (!have_blocked_ && !have_sn_) {
-        stage_supernodal();
-        if (use_sn_) {
-            build_supernodal();
-            have_sn_ = true;
-        } else {
-            build_blocked();
-            have_blocked_ = true;
-        }
+    if (!have_blocked_) {
+        build_blocked();
+        have_blocked_ = true;
     }
-    const i64 rows = have_sn_ ? sn_.scratch_rows : blocked_.scratch_rows;
+    const i64 rows = blocked_.scratch_rows;
     if (rows) {
         const size_t want = (size_t)rows * (size_t)total_cols;
-        const bool fresh = want > scratch_.size() || !scratch_.get();
         scratch_.resize(want);
-        // scratch row 0 of the supernodal programme is a row of zeros that nothing ever writes
-        if (have_sn_ && (fresh || scratch_cols_ != total_cols)) RSP_HIP(hipMemset(scratch_.get(), 0, (size_t)total_cols * sizeof(double)));
         scratch_cols_ = total_cols;
     }
 }
@@ -655,10 +472,6 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
                            double *scratch_override)
 {
     if (!scratch_override) prepare_blocked(total_cols);
-    if (have_sn_) {
-        run_window_supernodal(X, ld, nrhs, col_off, total_cols, stream, after_heavy, scratch_override ? scratch_override : scratch_.get());
-        return;
-    }
     const BlockedProgram &P = blocked_;
     double *const Sbase = scratch_override ? scratch_override : scratch_.get();
     double *const Sw = Sbase ? Sbase + col_off : nullptr;
@@ -723,21 +536,7 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
             recorded = true;
         }
         done += level_work(lv);
-        if (lv.nclusters && P.dense) {  // dense tasks: one single-wavefront workgroup per (task, 16 * NT columns)
-            const i64 dense_nt = std::max<i64>(1, std::min<i64>(4, env_or("RSP_DENSE_NT", kDenseNT)));
-            const int nt = dense_nt >= 4 ? 4 : dense_nt >= 2 ? 2 : 1;
-            const int rb = 16 * nt;
-            const int dchunks = (int)((nrhs + rb - 1) / rb);
-            const bool dfast = fast && nrhs % rb == 0;
-            const dev::DenseArrays DA{P.clusters.get(), P.cluster_ids.get(), P.dense_steps.get(), P.dense_coef.get()};
-            const i64 wgs = ((i64)lv.nclusters * dchunks + 7) / 8 * 8;
-            const size_t lds_bytes = (size_t)(P.cluster_slots + 1) * rb * 8;
-            auto kernel = nt == 4 ? (dfast ? dev::solve_dense_tasks<4, true> : dev::solve_dense_tasks<4, false>)
-                        : nt == 2 ? (dfast ? dev::solve_dense_tasks<2, true> : dev::solve_dense_tasks<2, false>)
-                                  : (dfast ? dev::solve_dense_tasks<1, true> : dev::solve_dense_tasks<1, false>);
-            hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(64), lds_bytes, stream, DA, lv.cluster_begin, lv.nclusters, dchunks, X, ld, Sw, lds,
-                               (int)nrhs);
-        } else if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
+        if (lv.nclusters) {  // clusters and block tasks of one level are independent of each other
             const int cpw = (int)std::min<i64>(std::min<i64>(nchunks, 4), cluster_cpw);
             const size_t per_wave = (size_t)P.cluster_slots * 512 + 1024;
             const i64 wgs = ((i64)lv.nclusters * ((nchunks + cpw - 1) / cpw) + 7) / 8 * 8;  // whole rounds over the 8 XCDs
@@ -884,12 +683,10 @@ static double *noalloc_scratch_for_current_device()
 int TriSolver::solve_device_noalloc(double *X, i64 ld, i64 nrhs, hipStream_t stream)
 {
     if (nrhs <= 0 || n_ == 0) return kOk;
-    if (!have_blocked_ && !have_sn_) return kBadInput;  // building and uploading the programme allocates: an earlier solve must have done it
-    const i64 rows = have_sn_ ? sn_.scratch_rows : blocked_.scratch_rows;
+    if (!have_blocked_) return kBadInput;  // building and uploading the programme allocates: an earlier solve must have done it
+    const i64 rows = blocked_.scratch_rows;
     if (rows > 0 && rows > kNoAllocScratchDoubles / nrhs) return kBadInput;
     double *S = noalloc_scratch_for_current_device();
-    // the supernodal programme pads its input lists with scratch row 0, a row of zeros: the array keeps the last call's contents
-    if (have_sn_) RSP_HIP(hipMemsetAsync(S, 0, (size_t)nrhs * sizeof(double), stream));
     run_window(X, ld, nrhs, 0, nrhs, stream, nullptr, S);
     return kOk;
 }

@@ -127,12 +127,10 @@ inline void sort_triples(std::vector<Triple> &src)  // by (pos, slot); most call
 
 class Builder {
    public:
-    Builder(const GatherForm &G, i64 max_blocks, int slots, bool dense)
-        : G_(G), n_(G.n), max_blocks_(std::max<i64>(1, max_blocks)),
-          slots_(dense ? std::min(slots, 4096) : std::min(slots, 64)),  // group-record clusters: one id per lane
-          dense_(dense), recipe_ok_(G.keep_src && !dense)
+    Builder(const GatherForm &G, i64 max_blocks, int slots)
+        : G_(G), n_(G.n), max_blocks_(std::max<i64>(1, max_blocks)), slots_(std::min(slots, 64)),  // group-record clusters: one id per lane
+          recipe_ok_(G.keep_src)
     {
-        P_.dense = dense;
         avail_.assign(n_, 0);
         task_of_.assign(n_, -1);
         stamp_.assign(n_, -1);
@@ -145,7 +143,6 @@ class Builder {
         tune("RSP_SPLIT8_SOURCES", split8_sources_);
         tune("RSP_BIG_CHAIN", big_chain_);
         tune("RSP_MAX_BLOCK_SOURCES", max_block_sources_);
-        if (const char *e = std::getenv("RSP_DENSE_FILL")) dense_fill_ = std::atof(e);
         emit_threads_ = host_threads();  // RSP_EMIT_THREADS=0: the sequential path (the programme does not depend on it)
         tune("RSP_EMIT_THREADS", emit_threads_);
         tune("RSP_ITEM_ROWS", item_rows_);
@@ -184,7 +181,7 @@ class Builder {
         }
         clock_.lap(1);
         finish();
-        P_.refill.valid = recipe_ok_ && !dense_ && (i64)G_.idx.size() + n_ + P_.refill.pool_size < INT32_MAX;
+        P_.refill.valid = recipe_ok_ && (i64)G_.idx.size() + n_ + P_.refill.pool_size < INT32_MAX;
         if (!P_.refill.valid) P_.refill = BlockProgram::Refill();
         clock_.lap(2);
         if (std::getenv("RSP_TIMING"))
@@ -283,149 +280,8 @@ class Builder {
         return hi - lo + 1 + ext;
     }
 
-    // ---- dense task: the cluster's unknowns as nodes of up to 16, each one dense matrix-core product (sparse.hpp) ----
-    void emit_dense_task(int32_t c)
-    {
-        close_task();
-        const i64 lo = cluster_lo_[c], hi = cluster_hi_[c];
-        const i64 n_own = hi - lo + 1;
-        if (slot_.empty()) slot_.assign(n_, -1);
-        std::vector<int32_t> ext;
-        ++stamp_id_;
-        i64 level = 0;
-        for (i64 k = 0; k < n_own; ++k) {
-            const i64 r = G_.descending ? hi - k : lo + k;
-            for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
-                const i64 s = G_.idx[p];
-                if (s >= lo && s <= hi) continue;
-                if (stamp_[s] != stamp_id_) {
-                    stamp_[s] = stamp_id_;
-                    slot_[s] = (int32_t)ext.size();
-                    ext.push_back((int32_t)s);
-                    level = std::max<i64>(level, avail_[s] + 1);
-                }
-            }
-        }
-        const int32_t n_ext = (int32_t)ext.size();
-        const int32_t zero_slot = n_ext + (int32_t)n_own;
-        ClusterHeader h{n_ext, (int32_t)n_own, 0, 0, (i64)P_.cluster_ids.size(), (i64)P_.dense_meta.size()};
-        P_.cluster_ids.insert(P_.cluster_ids.end(), ext.begin(), ext.end());
-        for (i64 k = 0; k < n_own; ++k) {
-            const i64 r = G_.descending ? hi - k : lo + k;
-            slot_[r] = n_ext + (int32_t)k;
-            P_.cluster_ids.push_back((int32_t)r);
-        }
-        auto row_of = [&](i64 k) { return G_.descending ? hi - k : lo + k; };
-        std::vector<int32_t> uni;      // distinct source slots of the node being formed
-        std::vector<double> T, Ti, Cf, As;
-        for (i64 k0 = 0; k0 < n_own;) {
-            // greedy node: add unknowns while the dense tile [rows x distinct sources] stays reasonably full
-            const int32_t first_own = n_ext + (int32_t)k0;
-            ++stamp_id_;
-            uni.clear();
-            i64 entries = 0, k1 = k0;
-            while (k1 < n_own && k1 - k0 < 16) {
-                const i64 r = row_of(k1);
-                i64 add_uni = 0, add_ent = 0;
-                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
-                    const int32_t sl = slot_[G_.idx[p]];
-                    if (sl >= first_own) continue;  // inside the node
-                    ++add_ent;
-                    if (stamp_[G_.idx[p]] != stamp_id_) ++add_uni;  // counted again below if accepted
-                }
-                const i64 rows = k1 - k0 + 1, nu = (i64)uni.size() + add_uni;
-                if (k1 > k0 && nu > 0 && (double)(entries + add_ent) < dense_fill_ * (double)(rows * nu)) break;
-                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
-                    const i64 s = G_.idx[p];
-                    if (slot_[s] >= first_own) continue;
-                    if (stamp_[s] != stamp_id_) {
-                        stamp_[s] = stamp_id_;
-                        uni.push_back(slot_[s]);
-                    }
-                }
-                entries += add_ent;
-                ++k1;
-            }
-            const int w = (int)(k1 - k0);
-            std::sort(uni.begin(), uni.end());
-            const int ns = (int)uni.size();
-            // in-node triangle and source coefficients (duplicate entries add up, as the sequential loops would)
-            T.assign((size_t)w * w, 0.0);
-            Cf.assign((size_t)w * std::max(ns, 1), 0.0);
-            for (int a = 0; a < w; ++a) {
-                const i64 r = row_of(k0 + a);
-                T[(size_t)a * w + a] = G_.diag[r];
-                for (i64 p = G_.ptr[r]; p < G_.ptr[r + 1]; ++p) {
-                    const int32_t sl = slot_[G_.idx[p]];
-                    if (sl >= first_own) {
-                        T[(size_t)a * w + (sl - first_own)] += G_.val[p];
-                    } else {
-                        const int e = (int)(std::lower_bound(uni.begin(), uni.end(), sl) - uni.begin());
-                        Cf[(size_t)a * ns + e] += G_.val[p];
-                    }
-                }
-            }
-            Ti.assign((size_t)w * w, 0.0);
-            for (int cc = 0; cc < w; ++cc) {
-                Ti[(size_t)cc * w + cc] = 1.0 / T[(size_t)cc * w + cc];
-                for (int a = cc + 1; a < w; ++a) {
-                    double sum = 0.0;
-                    for (int t = cc; t < a; ++t) sum += T[(size_t)a * w + t] * Ti[(size_t)t * w + cc];
-                    Ti[(size_t)a * w + cc] = -sum / T[(size_t)a * w + a];
-                }
-            }
-            As.assign((size_t)w * std::max(ns, 1), 0.0);  // -T^-1 Cf
-            for (int a = 0; a < w; ++a)
-                for (int t = 0; t <= a; ++t) {
-                    const double ti = Ti[(size_t)a * w + t];
-                    if (ti == 0.0) continue;
-                    for (int e = 0; e < ns; ++e) As[(size_t)a * ns + e] -= ti * Cf[(size_t)t * ns + e];
-                }
-            // k-steps: the node's own unknowns first, then its sources; 4 rows of the B operand each
-            const int own_steps = (w + 3) / 4, src_steps = (ns + 3) / 4, steps = own_steps + src_steps;
-            for (int q = 0; q < steps; ++q) {
-                const bool own = q < own_steps;
-                const int base = own ? 4 * q : 4 * (q - own_steps);
-                for (int g = 0; g < 4; ++g) {
-                    const int e = base + g;
-                    int32_t sl = zero_slot;
-                    if (own ? e < w : e < ns) sl = own ? first_own + e : uni[e];
-                    P_.dense_slots.push_back((uint16_t)sl);
-                }
-                const size_t at = P_.dense_coef.size();
-                P_.dense_coef.resize(at + 64, 0.0);
-                for (int g = 0; g < 4; ++g) {
-                    const int e = base + g;
-                    if (!(own ? e < w : e < ns)) continue;
-                    for (int a = 0; a < w; ++a)
-                        P_.dense_coef[at + (size_t)g * 16 + a] = own ? Ti[(size_t)a * w + e] : As[(size_t)a * ns + e];
-                }
-                P_.dense_meta.push_back(q + 1 == steps ? (int32_t)(0x80000000u | ((uint32_t)w << 20) | (uint32_t)first_own) : 0);
-            }
-            P_.padded_entries += (i64)steps * 64;
-            P_.dense_nodes++;
-            for (i64 k = k0; k < k1; ++k) {
-                const i64 r = row_of(k);
-                avail_[r] = (int32_t)level;
-                task_of_[r] = -2;
-                P_.cluster_entries += G_.ptr[r + 1] - G_.ptr[r];
-            }
-            k0 = k1;
-        }
-        h.ngroups = (int32_t)((i64)P_.dense_meta.size() - h.grp_off);
-        P_.clusters.push_back(h);
-        cluster_level_.push_back((int32_t)level);
-        emit_order_.push_back(c);
-        P_.cluster_rows += n_own;
-        P_.cluster_slots = std::max<int32_t>(P_.cluster_slots, n_ext + (int32_t)n_own);
-    }
-
     void emit_cluster(int32_t c)
     {
-        if (dense_) {
-            emit_dense_task(c);
-            return;
-        }
         close_task();
         const i64 lo = cluster_lo_[c], hi = cluster_hi_[c];
         const i64 n_own = hi - lo + 1;
@@ -1464,8 +1320,6 @@ class Builder {
     const GatherForm &G_;
     const i64 n_, max_blocks_;
     const int slots_;
-    const bool dense_;
-    double dense_fill_ = 0.3;  // a node keeps growing while its [rows x distinct sources] tile is at least this full
     i64 split_sources_ = kSplitSources, split8_sources_ = 4 * kSplitSources, big_chain_ = kBigChain, max_block_sources_ = kMaxBlockSources;
     BlockProgram P_;
     std::vector<int32_t> avail_, task_of_, cluster_of_, slot_;
@@ -1557,9 +1411,9 @@ bool refill_block_program(const GatherForm &G, BlockProgram &P)
     return true;
 }
 
-BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots, bool dense)
+BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots)
 {
-    Builder b(G, max_task_blocks, cluster_slots, dense);
+    Builder b(G, max_task_blocks, cluster_slots);
     return b.run();
 }
 
@@ -1601,66 +1455,10 @@ ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P, bo
         for (i64 c = P.cluster_level_ptr[l]; c < P.cluster_level_ptr[l + 1]; ++c) {
             const ClusterHeader &h = P.clusters[c];
             const i64 ns = h.n_ext + h.n_own;
-            const i64 stream_len = P.dense ? (i64)P.dense_meta.size() : (i64)P.groups.size();
+            const i64 stream_len = (i64)P.groups.size();
             if (ns > P.cluster_slots || h.ids_off < 0 || h.ids_off + ns > (i64)P.cluster_ids.size() || h.grp_off < 0 ||
                 h.grp_off + h.ngroups > stream_len || h.ngroups < 1) {
                 ++R.bad_index;
-                continue;
-            }
-            if (P.dense) {  // replay of dev::solve_dense_tasks: k-steps accumulate, the last one of a node stores
-                if (P.dense_slots.size() != 4 * P.dense_meta.size() || P.dense_coef.size() != 64 * P.dense_meta.size() || ns + 1 > 65535) {
-                    ++R.bad_index;
-                    continue;
-                }
-                std::vector<double> lds(ns + 1, 0.0);
-                std::vector<char> final_slot(ns + 1, 0);
-                bool ok = true;
-                for (i64 s = 0; s < ns; ++s) {
-                    const int32_t id = P.cluster_ids[h.ids_off + s];
-                    if (id < 0 || id >= n) { ++R.bad_index; ok = false; break; }
-                    if (s < h.n_ext && xdone[id] >= l) ++R.order_violations;
-                    if (s >= h.n_ext && xdone[id] != INT32_MAX) ++R.unwritten;
-                    lds[s] = x[id];
-                    final_slot[s] = s < h.n_ext;
-                }
-                if (!ok) continue;
-                final_slot[ns] = 1;  // the row of zeros
-                double acc[16];
-                std::fill(acc, acc + 16, 0.0);
-                i64 next_out = h.n_ext;
-                for (i64 qs = h.grp_off; qs < h.grp_off + h.ngroups;) {
-                    i64 qe = qs;
-                    while (qe < h.grp_off + h.ngroups && P.dense_meta[qe] >= 0) ++qe;
-                    if (qe == h.grp_off + h.ngroups) { ++R.bad_index; break; }  // k-steps without a closing node
-                    const int32_t m = P.dense_meta[qe];
-                    const i64 w = (m >> 20) & 31, out = m & 0xFFFFF;
-                    if (w < 1 || w > 16 || out != next_out || out + w > ns) { ++R.bad_index; break; }
-                    for (i64 q = qs; q <= qe; ++q)
-                        for (int g = 0; g < 4; ++g) {
-                            const i64 sl = P.dense_slots[4 * q + g];
-                            if (sl > ns) { ++R.bad_index; continue; }
-                            bool used = false;
-                            for (int a = 0; a < 16; ++a) {
-                                const double cf = P.dense_coef[64 * q + 16 * g + a];
-                                used = used || cf != 0.0;
-                                if (a >= w && cf != 0.0) ++R.bad_index;  // rows beyond the node are never stored
-                                acc[a] += cf * lds[sl];
-                            }
-                            // a source must be final; the node's own slots hold the right-hand sides it is about to replace
-                            if (used && !final_slot[sl] && !(sl >= out && sl < out + w)) ++R.order_violations;
-                        }
-                    for (i64 a = 0; a < w; ++a) { lds[out + a] = acc[a]; final_slot[out + a] = 1; }
-                    next_out = out + w;
-                    std::fill(acc, acc + 16, 0.0);
-                    qs = qe + 1;
-                }
-                if (next_out != ns) ++R.unwritten;
-                for (i64 s = h.n_ext; s < ns; ++s) {
-                    const int32_t id = P.cluster_ids[h.ids_off + s];
-                    x[id] = lds[s];
-                    xdone[id] = l;
-                    writes[id]++;
-                }
                 continue;
             }
             std::vector<double> lds(ns);

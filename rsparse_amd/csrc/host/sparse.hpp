@@ -213,20 +213,6 @@ struct BlockProgram {
     std::vector<int32_t> cluster_ids;
     std::vector<GroupRec> groups;
     int32_t cluster_slots = 0;       // LDS slots a wavefront needs (max n_ext + n_own over all clusters)
-    // DENSE TASKS (dense == true): the clusters are larger (hundreds of slots) and their arithmetic is not a stream of
-    // group records but a stream of matrix-core K-STEPS (v_mfma_f64_16x16x4_f64, 16 right-hand sides per n-tile).  The
-    // unknowns of a task are cut into NODES of up to 16 consecutive unknowns; a node with in-node triangle T and
-    // source coefficients Cf (sources = earlier slots of the task) is applied as ONE dense product
-    //     x_node = [ T^-1 | -T^-1 Cf ] * [ b_node ; x_sources ]
-    // so nothing inside a node is sequential.  Per k-step: 4 slot numbers (the rows of the B operand; slot
-    // n_ext + n_own is a row of zeros used as padding), 64 doubles of the A operand in lane order (lane i + 16 g holds
-    // A[i][4 k + g]) and a meta word: 0, or for the LAST k-step of a node  1 << 31 | rows << 20 | first output slot.
-    // ClusterHeader is reused: ngroups = number of k-steps, grp_off = first k-step of the task.
-    bool dense = false;
-    std::vector<uint16_t> dense_slots;
-    std::vector<int32_t> dense_meta;
-    std::vector<double> dense_coef;
-    i64 dense_nodes = 0;
     // schedule
     std::vector<i64> task_ptr;       // blocks of task t: [task_ptr[t], task_ptr[t+1]) (executed in order by one wavefront)
     std::vector<i64> level_ptr;      // block tasks of level l
@@ -242,7 +228,7 @@ struct BlockProgram {
     // refactorisation) are poured into coef and groups without emitting the programme again (refill_block_program).
     // A source code is -1 (a constant: padding, the -1 of a partial-sum combine), an entry of the gather form
     // [0, nnz): G.val[code], a diagonal [nnz, nnz + n): G.diag[code - nnz], or an entry of a chain inverse
-    // [nnz + n, ...): -pool[code - nnz - n].  valid == false (duplicate entries that add up, dense tasks, more than 2^31
+    // [nnz + n, ...): -pool[code - nnz - n].  valid == false (duplicate entries that add up, more than 2^31
     // codes): the programme is emitted again instead.
     struct Refill {
         bool valid = false;
@@ -273,75 +259,7 @@ constexpr i64 kMaxBlockSources = 1024;  // longer source lists become partial su
 constexpr int kClusterSlots = 24;    // default LDS slots per cluster (12 KB per wavefront at 64 right-hand sides; measured
                                      // at C2: 24 slots beat 16, 32, 40 and 48 -- occupancy outweighs coverage)
 constexpr i64 kTaskBlocks = 1;       // default number of dependent blocks one wavefront runs back to back (measured: 1 beats 2, 3)
-constexpr int kDenseSlots = 288;     // default LDS slots of a dense task (36 KB per wavefront at 16 right-hand sides)
-BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots, bool dense = false);
-
-// ---- supernodal.cpp -------------------------------------------------------------------------------
-// The SUPERNODAL multi-right-hand-side programme: the factor's column structure is cut into
-//   * TASKS at the bottom of the dependency forest: whole subtrees whose rows of X fit in LDS.  The bottom is very
-//     sparse (a handful of entries per unknown), so a task is a stream of scalar multiply-subtract records, level by
-//     level, four unknowns of a level at a time (kernel dev::solve_sparse_tasks), and
-//   * NODES above them: runs of consecutive columns with nested structure (the supernodes of a Cholesky factor, relaxed
-//     for anything else).  A node with diagonal block D (w x w) and rows E below it (m of them, T_E = T[E, node]) is
-//     applied as dense products with D^-1 folded in, so nothing inside a node is sequential:
-//         gather kinds  (ltsolve, utsolve):  x_node = D^-T b_node - (T_E D^-1)^T x_E
-//         scatter kinds (lsolve, usolve):    y = b_node - (partial rows sent by earlier units);  x_node = D^-1 y;
-//                                            partial rows for E:  u_E = (T_E D^-1) y      (atomics-free fan-out)
-//     Wide nodes (w > kSnSmallNode) keep D^-1 and T_E apart (two dependent products) so that the host never forms
-//     T_E D^-1 for them.
-// Everything a node does is a list of ITEMS, each one generic product  OUT = INIT + A * IN  over rows named by ids
-// (id >= 0: row of X, id < 0: scratch row ~id; scratch row 0 is a row of zeros used as padding), at most 64 output rows
-// per item, executed by dev::sn_gemm on the matrix cores with 64 x 64 register tiles.  Items and tasks carry a level;
-// a level is one launch of each kernel.
-struct SnItem {            // 48 bytes
-    int32_t m_tiles;       // 1..4 tiles of 16 output rows
-    int32_t k_steps;       // input rows / 4 (padded with the zero row)
-    int32_t nsplit;        // wavefronts of the workgroup that share the k-steps (1, 2 or 4)
-    int32_t has_init;
-    i64 a_off;             // into coef: [k_step][row tile][64] doubles, lane i + 16 g <-> A[16 tile + i][4 k_step + g]
-    i64 out_off;           // into ids: 16 * m_tiles output rows (kNone: padding, not stored)
-    i64 in_off;            // into ids: 4 * k_steps input rows
-    i64 init_off;          // into ids: 16 * m_tiles rows the accumulators start from (kNone: 0.0)
-};
-// One (step, lane group) of a task's arithmetic: the four lane groups of a wavefront (16 right-hand sides each) work on
-// four different unknowns of the same dependency level at once.
-struct SnTaskRec {      // 16 bytes
-    double coef;        // kEntry: T[row, source]; kEnd: 1 / diagonal (1.0 for a partial row)
-    uint32_t slot;      // kEntry: slot of the source; kBegin / kEnd: slot of the unknown itself (kBegin of a partial row: the zero slot)
-    uint32_t op;        // (all four dwords are used by the kernel: a dead dword would be reused as a temporary while the load is in flight)
-    static constexpr uint32_t kNothing = 0, kEntry = 1 /* acc -= coef * x[slot] */, kBegin = 2 /* acc = x[slot] */,
-                              kEnd = 3 /* x[slot] = acc * coef */;
-};
-struct SnProgram {
-    static constexpr int32_t kNone = INT32_MIN;
-    i64 n = 0;
-    bool scatter = false;
-    std::vector<SnItem> items;            // sorted by level
-    std::vector<i64> item_level_ptr;      // items of level l
-    std::vector<int32_t> ids;
-    std::vector<double> coef;
-    std::vector<ClusterHeader> tasks;     // sorted by level; ngroups = steps (a multiple of kTaskWindow), grp_off = first step
-    std::vector<i64> task_level_ptr;
-    std::vector<int32_t> task_ids;        // id >= 0: row of X (loaded and, for own slots, stored); id < 0: scratch row (starts at 0.0, stored)
-    std::vector<SnTaskRec> task_recs;     // 4 per step (one per lane group); a task's steps: [grp_off, grp_off + ngroups)
-    int32_t task_slots_max = 0;
-    i64 scratch_rows = 1;                 // row 0: zeros
-    // statistics
-    i64 nnodes = 0, big_nodes = 0, task_rows = 0, top_rows = 0, padded_flops_per_col = 0, partial_rows = 0;
-};
-struct SnOptions {
-    int task_slots = 160;        // LDS slots of a task (at most 319)
-    i64 small_node = 64;         // wider nodes are cut into wide_rows-row items with input lists of at most wide_item_k
-    i64 wide_rows = 16;
-    i64 wide_item_k = 256;
-    i64 max_node = 1024;         // widest node (the host inverts its diagonal block: O(w^3))
-    i64 max_item_k = 512;        // longer input lists are cut into partial products plus a combine item
-    double relax = 0.05;         // zeros a node may take in per real entry when it absorbs the next column
-};
-constexpr int kTaskWindow = 4;   // steps a wavefront processes together (their LDS reads are issued before any of them is used)
-constexpr int kTaskDepth = 6;    // windows of records in flight; a task's steps are padded to whole rings (kTaskWindow * kTaskDepth)
-// R: gather form of the solve kind; C: gather form of the dual kind (kind ^ 1; needed for the scatter kinds 0 and 2 only)
-SnProgram build_supernodal_program(const GatherForm &R, const GatherForm *C, bool scatter, const SnOptions &opt);
+BlockProgram build_block_program(const GatherForm &G, i64 max_task_blocks, int cluster_slots);
 
 // Host-side validator of a programme (debug aid, never a solve path: it takes no user data).  Replays the programme
 // level by level on ONE synthetic right-hand side with every index bounds-checked and every read checked against the
@@ -354,6 +272,5 @@ struct ProgramReport {
 };
 // items_view: the wide items run as items (dev::solve_items) instead of as their row tiles
 ProgramReport check_block_program(const GatherForm &G, const BlockProgram &P, bool items_view = false);
-ProgramReport check_supernodal_program(const GatherForm &R, const SnProgram &P);
 
 }  // namespace rsp

@@ -240,22 +240,16 @@ def test_trisolve_multi_rhs_vs_oracle(kind, fac, nrhs):
         assert rel_inf(y[:, 0], 3.0 * X[:, 0] + X[:, 1]) <= 1e-9
 
 
-# the supernodal programme forced on every kind of factor (by default only factors that need few launches take it), in its
-# default shape and in a shape with small tasks, wide (unfolded) nodes and partial products with combine items
-@pytest.mark.parametrize("shape", [{}, {"RSP_SN_TASK_SLOTS": "40", "RSP_SN_SMALL_NODE": "8", "RSP_SN_MAX_ITEM_K": "32", "RSP_DENSE_NT": "2"}])
-@pytest.mark.parametrize("programme", ["1", "0", "dense"])
+# the blocked programme with wide items forced on every chain of every kind of factor, run as items and as their twin blocks
+@pytest.mark.parametrize("waves", ["1", "0"])
 @pytest.mark.parametrize("kind,fac", KINDS)
-def test_trisolve_both_programmes_vs_oracle(kind, fac, programme, shape, monkeypatch):
-    if programme != "1" and shape:
-        pytest.skip("the shape switches only affect the supernodal programme")
-    monkeypatch.setenv("RSP_SUPERNODAL", "1" if programme == "1" else "0")
-    if programme == "dense":  # the blocked programme with dense matrix-core tasks in place of its group-record clusters
-        monkeypatch.setenv("RSP_DENSE_TASKS", "1")
-    for k, v in shape.items():
-        monkeypatch.setenv(k, v)
+def test_trisolve_items_and_twins_vs_oracle(kind, fac, waves, monkeypatch):
+    monkeypatch.setenv("RSP_ITEM_MIN_SOURCES", "1")
+    monkeypatch.setenv("RSP_ITEM_MIN_FILL", "0")
+    monkeypatch.setenv("RSP_ITEM_WAVES", waves)
     T = factors()[fac]
     n = T[0]
-    for nrhs in (3, 64, 200):
+    for nrhs in (3, 64, 200, 256):
         B = np.asfortranarray((2.0 * synth.splitmix64(11, n * nrhs) - 1.0).reshape(nrhs, n).T)
         want = np.stack([orc.trisolve(kind, T, B[:, r]) for r in (0, nrhs // 2, nrhs - 1)], axis=1)
         h = rs.TriHandle(T, KIND_ID[kind])

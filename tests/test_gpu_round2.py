@@ -579,6 +579,9 @@ def test_wide_items_vs_oracle(monkeypatch):
         assert info["items"] > 0, info
 
 
+@pytest.mark.parametrize("env", [{"RSP_CHOL_GROUPED": "0"}, {"RSP_CHOL_TINY": "0"}, {"RSP_CHOL_FUSE_WAVES": "0"}, {"RSP_CHOL_FUSE_WAVES": "100000"},
+                                 {"RSP_CHOL_SHORT_GROUPS": "0"}, {"RSP_CHOL_BLOCK_PANELS": "1"}],
+                         ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_every_cholesky_variant_vs_oracle(env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -169,8 +169,8 @@ def _program_factors():
     return [(0, L), (1, L), (0, f["L"]), (1, f["L"]), (2, f["U"]), (3, f["U"]), (0, g["L"]), (2, g["U"]), (3, g["U"])]
 
 
-# cluster_slots > 0: group-record clusters; < 0: dense matrix-core tasks of that many LDS slots; 0: the library default
-@pytest.mark.parametrize("task_blocks,cluster_slots", [(0, 0), (1, 16), (4, 96), (2, 1), (1, -17), (1, -40), (2, -288), (1, -1000)])
+# cluster_slots > 0: group-record clusters of that many LDS slots; 0: the library default
+@pytest.mark.parametrize("task_blocks,cluster_slots", [(0, 0), (1, 16), (4, 96), (2, 1)])
 def test_block_programme_is_valid_and_exact(task_blocks, cluster_slots):
     """Every id in range, every row read only after the level that writes it, every unknown written exactly once,
     and the replayed programme agrees with sequential substitution (rsp_tri_validate_program)."""
@@ -182,39 +182,20 @@ def test_block_programme_is_valid_and_exact(task_blocks, cluster_slots):
             assert rep["clusters"] == 0
 
 
-# (task slots, widest folded node, widest node, longest input list): defaults, then shapes that force wide nodes, partial
-# products with combine items, and no tasks at all
-@pytest.mark.parametrize("opts", [(0, 0, 0, 0), (40, 8, 64, 32), (-1, 4, 16, 16), (17, 64, 1024, 512)])
-def test_supernodal_programme_is_valid_and_exact(opts):
-    """The supernodal programme (dense LDS tasks + supernode products, host/supernodal.cpp) replayed on the host: every id in
-    range, nothing read at the level that writes it, every unknown written exactly once, and the result equal to
-    sequential substitution (rsp_tri_validate_supernodal), for Cholesky and LU factors in all four solve kinds."""
+@pytest.mark.parametrize("env", [{"RSP_ITEM_MIN_SOURCES": "1", "RSP_ITEM_MIN_FILL": "0"},
+                                 {"RSP_ITEM_MIN_SOURCES": "1", "RSP_ITEM_MIN_FILL": "0", "RSP_ITEM_ROWS": "32", "RSP_SORT_ROWS": "0"},
+                                 {"RSP_ITEM_MIN_SOURCES": "1", "RSP_ITEM_MIN_FILL": "0", "RSP_MAX_BLOCK_SOURCES": "48", "RSP_BIG_CHAIN": "8"},
+                                 {"RSP_ITEM_ROWS": "16"}])
+def test_block_programme_with_wide_items_is_valid_in_both_views(env, monkeypatch):
+    """Round 3: wide items over every chain (however short and sparse, over partial sums too), the programme replayed once
+    with the items as their twin blocks and once as items (masks, compressed coefficient blocks): both views valid and
+    equal to sequential substitution; rows of a chain regrouped by similarity or in natural order."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     for kind, T in _program_factors():
-        rep = rs.validate_supernodal(T, kind, *opts)
+        rep = rs.validate_program(T, kind, 0, 0)
         assert rep["bad_index"] == 0 and rep["order_violations"] == 0 and rep["unwritten"] == 0, (kind, rep)
         assert rep["max_rel_error"] <= 1e-12, (kind, rep)
-        if opts[0] < 0:
-            assert rep["tasks"] == 0
-
-
-def test_supernodal_programme_with_duplicate_entries_and_tiny_systems():
-    A = synth.laplacian_2d(30, 25)
-    st, L = orc.chol(A, orc.schol(A, 0))
-    n, _, p, i, x = L
-    pi, ii, xi = [0], [], []
-    for j in range(n):  # every off-diagonal entry twice, with different halves (the reference applies both)
-        rows, vals = i[p[j]:p[j + 1]], x[p[j]:p[j + 1]]
-        ii += [rows[0]] + [r for r in rows[1:] for _ in (0, 1)]
-        xi += [vals[0]] + [v * f for v in vals[1:] for f in (0.25, 0.75)]
-        pi.append(len(ii))
-    D = (n, n, np.array(pi, np.int64), np.array(ii, np.int64), np.array(xi))
-    one = rs.Sprs.from_vec([[4.0]])
-    two = rs.Sprs.from_vec([[2.0, 0.0], [1.0, 3.0]])
-    for kind in (0, 1):
-        for T, opts in ((D, (0, 0, 0, 0)), (D, (24, 4, 32, 16)), (one, (0, 0, 0, 0)), (two, (0, 0, 0, 0)), (two, (-1, 0, 0, 0))):
-            rep = rs.validate_supernodal(T, kind, *opts)
-            assert rep["bad_index"] == 0 and rep["order_violations"] == 0 and rep["unwritten"] == 0, rep
-            assert rep["max_rel_error"] <= 1e-12, rep
 
 
 def test_block_programme_with_duplicate_entries():
