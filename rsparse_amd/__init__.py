@@ -33,6 +33,7 @@ from .api import (  # noqa: F401
     lsolve,
     ltsolve,
     lu,
+    lu_static_pattern,
     lusol,
     qr,
     qrsol,

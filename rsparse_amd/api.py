@@ -118,6 +118,8 @@ def lib():
             "rsp_lu_L": (cint, [vp, csc]),
             "rsp_lu_U": (cint, [vp, csc]),
             "rsp_lu_pinv": (vp, [vp]),
+            "rsp_lu_on_device": (cint, [vp]),
+            "rsp_lu_static_pattern_f64": (cint, [csc, vp, C.POINTER(vp), C.POINTER(i64)]),
             "rsp_lu_solve_f64": (cint, [vp, vp, vp, i64, i64]),
             "rsp_lu_solve_dev_f64": (cint, [vp, vp, vp, cint, i64, i64, vp]),
             "rsp_gaxpy_f64": (cint, [csc, vp, vp, vp]),
@@ -406,6 +408,11 @@ class LuHandle:
     def pinv(self):
         return _vec(lib().rsp_lu_pinv(self._h), self._s.n, np.int64)
 
+    @property
+    def on_device(self):
+        """True when the values were computed by the GPU numeric LU (static pivots held), False: by the host routine."""
+        return bool(lib().rsp_lu_on_device(self._h))
+
     def solve(self, B):
         """B: float64, shape (n,) or Fortran-ordered (n, nrhs); overwritten with A^-1 B."""
         n = self._s.n
@@ -424,11 +431,22 @@ class LuHandle:
 
 
 def lu(a, s, tol):
-    """rsparse::lu (src/lib.rs:519): host LU with the reference's pivot rule; returns a handle with .l .u .pinv."""
+    """rsparse::lu (src/lib.rs:519): LU with the reference's pivot rule -- on the GPU when the diagonal pivots hold, else on
+    the host; returns a handle with .l .u .pinv (.on_device tells which)."""
     a = _as_sprs(a)
     h = C.c_void_p()
     _check(lib().rsp_lu_f64(C.byref(a._view()), s._h, tol, C.byref(h)))
     return LuHandle(h.value, s)
+
+
+def lu_static_pattern(a, s):
+    """The integer half of the GPU numeric LU on the host: (handle with the patterns of L, U and pinv for diagonal pivots,
+    values zero; depth of the column dependency levels)."""
+    a = _as_sprs(a)
+    h = C.c_void_p()
+    depth = C.c_int64(0)
+    _check(lib().rsp_lu_static_pattern_f64(C.byref(a._view()), s._h, C.byref(h), C.byref(depth)))
+    return LuHandle(h.value, s), depth.value
 
 
 def gaxpy(a, x, y):

@@ -79,6 +79,7 @@ struct rsp_lu {
     LuFactors f;
     std::unique_ptr<TriSolver> lower, upper;  // built on first solve
     bool single_use = false;                  // lusol: one solve, then dropped
+    bool on_device = false;                   // the values came from the GPU numeric LU (static pivots held), not from host/lu.cpp
     DeviceBuffer<int64_t> d_pinv, d_q;        // rsp_lu_solve_dev_f64: the two permutations on the device
     std::vector<int64_t> q_host;              // ... and what d_q holds
     DeviceBuffer<double> work;
@@ -1224,7 +1225,15 @@ int rsp_lu_f64(const rsp_csc_f64 *A, const rsp_symb *S, double tol, rsp_lu **N)
     *N = nullptr;
     return guarded([&] {
         std::unique_ptr<rsp_lu> h(new rsp_lu);
-        if (int st = sparse_lu(view_of(A), S->s.has_q ? S->s.q.data() : nullptr, tol, h->f)) return st;
+        const int64_t *q = S->s.has_q ? S->s.q.data() : nullptr;
+        // the numeric part on the GPU when every column keeps its diagonal as pivot (checked there) and the columns' dependency
+        // levels are wide enough to pay (RSP_LU_GPU: 0 never, 1 whenever applicable); bit-identical to the host's factors, which
+        // are what every other case gets
+        const char *mode = getenv("RSP_LU_GPU");
+        int st = lu_numeric_device(view_of(A), q, tol, h->f, mode && *mode ? atoi(mode) : 2);
+        h->on_device = st == kOk;
+        if (st == kLuDeclined) st = sparse_lu(view_of(A), q, tol, h->f);
+        if (st) return st;
         *N = h.release();
         return (int)RSP_OK;
     });
@@ -1253,6 +1262,22 @@ int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U)
     return RSP_OK;
 }
 const int64_t *rsp_lu_pinv(const rsp_lu *N) { return N ? N->f.pinv.data() : nullptr; }
+int rsp_lu_static_pattern_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_lu **N, int64_t *nlevels)
+{
+    if (!sane_indices(A) || !S || !N || A->m != A->n || S->s.n != A->n) return RSP_BAD_INPUT;
+    *N = nullptr;
+    return guarded([&] {
+        std::unique_ptr<rsp_lu> h(new rsp_lu);
+        std::vector<int32_t> level;
+        if (!lu_static_pattern(view_of(A), S->s.has_q ? S->s.q.data() : nullptr, h->f, level)) return (int)RSP_BAD_INPUT;
+        int32_t depth = 0;
+        for (int32_t l : level) depth = std::max(depth, l + 1);
+        if (nlevels) *nlevels = depth;
+        *N = h.release();
+        return (int)RSP_OK;
+    });
+}
+int rsp_lu_on_device(const rsp_lu *N) { return N && N->on_device ? 1 : 0; }
 
 // the two triangular handles of a factorisation, built on its first solve (caller holds the guard)
 static int lu_solvers(rsp_lu *N)

@@ -2,4 +2,5 @@
 #include "tri_engine.hip"
 #include "chol_engine.hip"
 #include "spmm_kernels.hip"
+#include "lu_engine.hip"
 #include "../capi.hip"

@@ -82,6 +82,11 @@ std::vector<i64> fundamental_supernodes(const std::vector<i64> &parent, const st
 // L/U storage order and values (compiled with -ffp-contract=off).
 int sparse_lu(const CscView &A, const i64 *q, double tol, LuFactors &out);
 
+// ---- lu_static.cpp --------------------------------------------------------------------------------
+// Patterns of L and U (reference storage order) and pinv of rsparse::lu when every column pivots on its diagonal (row q[k]),
+// plus the dependency level of every column; integer work only.  false: not applicable (see lu_static.cpp).
+bool lu_static_pattern(const CscView &A, const i64 *q, LuFactors &out, std::vector<int32_t> &level);
+
 // ---- schedule.cpp -------------------------------------------------------------------------------
 // 64-bit hash of a matrix's PATTERN (m, n, p[0..n], i[0..nnz)): what an analysis depends on.  Computed on the host threads
 // (chunks hashed independently and combined in order: the value does not depend on the thread count).

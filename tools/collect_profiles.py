@@ -11,7 +11,12 @@ PARTS = int(os.environ.get("RSP_PAIR_PARTS", "2"))
 
 tag, stats_dir = sys.argv[1], sys.argv[2]
 bench = json.load(open(sys.argv[3]))
-ours = lambda name: 'solve_level' in name or 'solve_clusters' in name
+ours = lambda name: 'solve_level' in name or 'solve_clusters' in name or 'solve_items' in name
+
+
+def kernel_class(nm):
+    return ('solve_items' if 'solve_items' in nm else 'solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else
+            'solve_level<deep ring, 16 columns>' if 'true, 1>' in nm else 'solve_level<deep ring, 64 columns>' if 'true, 4>' in nm else 'solve_level<lean>')
 
 
 def last_step(rows, key):
@@ -33,8 +38,7 @@ last = last_step([r for r in csv.DictReader(open(f)) if ours(r['Kernel_Name'])],
 by = collections.defaultdict(lambda: [0, 0.0])
 for r in last:
     nm = r['Kernel_Name']
-    k = ('solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else
-         'solve_level<deep ring, 16 columns>' if 'true, 1>' in nm else 'solve_level<deep ring, 64 columns>' if 'true, 4>' in nm else 'solve_level<lean>')
+    k = kernel_class(nm)
     by[k][0] += 1
     by[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 out["step"] = {"launches": len(last),
@@ -52,9 +56,7 @@ if len(sys.argv) > 5:
         acc = collections.Counter()
         for r in rs:
             nm = r['Kernel_Name']
-            k = ('solve_clusters' if 'clusters' in nm else 'solve_level_small' if 'small' in nm else
-                 'solve_level<deep ring, 16 columns>' if 'true, 1>' in nm else 'solve_level<deep ring, 64 columns>' if 'true, 4>' in nm else 'solve_level<lean>')
-            acc[k] += float(r['Counter_Value'])
+            acc[kernel_class(nm)] += float(r['Counter_Value'])
         return acc
     (fetch_kb, n1), (write_kb, n2) = total(sys.argv[4], 'FETCH_SIZE'), total(sys.argv[5], 'WRITE_SIZE')
     pf, pw = per_kernel(sys.argv[4], 'FETCH_SIZE'), per_kernel(sys.argv[5], 'WRITE_SIZE')
