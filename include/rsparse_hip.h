@@ -266,7 +266,14 @@ const int64_t *rsp_lu_pinv(const rsp_lu *N);   /* n entries */
  * rsparse::lu produces when every column pivots on its diagonal, values all zero; *nlevels = depth of the column dependency
  * levels.  RSP_BAD_INPUT when a diagonal entry is structurally missing (no static pivot sequence exists). */
 int rsp_lu_static_pattern_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_lu **N, int64_t *nlevels);
-int rsp_lu_on_device(const rsp_lu *N);         /* 1: the values came from the GPU numeric LU, 0: from the host routine */
+int rsp_lu_on_device(const rsp_lu *N);
+/* New values on the pattern the handle was made with: N becomes the factorisation of A (same p and i as the matrix given to
+ * rsp_lu_f64, RSP_BAD_INPUT otherwise; the column order of that call is kept).  No counterpart in the reference, which calls
+ * lu again (lib.rs:519); the result is what that call would give, bit for bit.  When N came from the GPU numeric LU the
+ * kernel alone runs again -- no depth-first search, no new analysis, resident solve programmes get the new coefficients --
+ * as long as every column still keeps its diagonal as pivot; otherwise the host routine factors A (the pivot sequence may
+ * change; solves are analysed again at their next use).  Not concurrent with solves on the same handle. */
+int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol);         /* 1: the values came from the GPU numeric LU, 0: from the host routine */
 /* b <- A^-1 b for nrhs host column-major right-hand sides (ipvec, lsolve, usolve, ipvec: src/lib.rs:678-681) */
 int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs);
 /* the same for a device-resident block in either rsp_layout, asynchronously on `stream`: both permutations run on the

@@ -119,6 +119,7 @@ def lib():
             "rsp_lu_U": (cint, [vp, csc]),
             "rsp_lu_pinv": (vp, [vp]),
             "rsp_lu_on_device": (cint, [vp]),
+            "rsp_lu_refactor_f64": (cint, [vp, csc, dbl]),
             "rsp_lu_static_pattern_f64": (cint, [csc, vp, C.POINTER(vp), C.POINTER(i64)]),
             "rsp_lu_solve_f64": (cint, [vp, vp, vp, i64, i64]),
             "rsp_lu_solve_dev_f64": (cint, [vp, vp, vp, cint, i64, i64, vp]),
@@ -412,6 +413,11 @@ class LuHandle:
     def on_device(self):
         """True when the values were computed by the GPU numeric LU (static pivots held), False: by the host routine."""
         return bool(lib().rsp_lu_on_device(self._h))
+
+    def refactor(self, a, tol):
+        """Factor `a` (same pattern as the matrix this handle was made from, new values) in place of the old factors."""
+        a = _as_sprs(a)
+        _check(lib().rsp_lu_refactor_f64(self._h, C.byref(a._view()), tol))
 
     def solve(self, B):
         """B: float64, shape (n,) or Fortran-ordered (n, nrhs); overwritten with A^-1 B."""

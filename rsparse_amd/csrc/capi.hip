@@ -80,6 +80,10 @@ struct rsp_lu {
     std::unique_ptr<TriSolver> lower, upper;  // built on first solve
     bool single_use = false;                  // lusol: one solve, then dropped
     bool on_device = false;                   // the values came from the GPU numeric LU (static pivots held), not from host/lu.cpp
+    std::unique_ptr<LuDevice> device;         // ... and its device half, for rsp_lu_refactor_f64
+    std::vector<int64_t> q_factor;            // the column order the factorisation was made with (empty: natural)
+    uint64_t pattern = 0;                     // pattern_hash of the matrix that was factored, and its entry count:
+    int64_t pattern_nnz = -1;                 // rsp_lu_refactor_f64 takes new values on that pattern only
     DeviceBuffer<int64_t> d_pinv, d_q;        // rsp_lu_solve_dev_f64: the two permutations on the device
     std::vector<int64_t> q_host;              // ... and what d_q holds
     DeviceBuffer<double> work;
@@ -1230,8 +1234,11 @@ int rsp_lu_f64(const rsp_csc_f64 *A, const rsp_symb *S, double tol, rsp_lu **N)
         // levels are wide enough to pay (RSP_LU_GPU: 0 never, 1 whenever applicable); bit-identical to the host's factors, which
         // are what every other case gets
         const char *mode = getenv("RSP_LU_GPU");
-        int st = lu_numeric_device(view_of(A), q, tol, h->f, mode && *mode ? atoi(mode) : 2);
+        int st = lu_numeric_device(view_of(A), q, tol, h->f, mode && *mode ? atoi(mode) : 2, &h->device);
         h->on_device = st == kOk;
+        if (q) h->q_factor.assign(q, q + A->n);
+        h->pattern = pattern_hash(view_of(A));
+        h->pattern_nnz = A->p[A->n];
         if (st == kLuDeclined) st = sparse_lu(view_of(A), q, tol, h->f);
         if (st) return st;
         *N = h.release();
@@ -1279,11 +1286,58 @@ int rsp_lu_static_pattern_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_lu **
 }
 int rsp_lu_on_device(const rsp_lu *N) { return N && N->on_device ? 1 : 0; }
 
+// New values on the pattern the handle was made with (a refactorisation; no counterpart in the reference, which runs lu
+// again).  With the device half present the kernel alone runs -- no depth-first search, nothing analysed again, the
+// solve programmes receive the new coefficients in place -- and the factors are again bit-identical to rsparse::lu's.
+// When a column no longer keeps its diagonal as pivot, or the handle came from the host routine, the host routine
+// factors the new matrix (the pivot sequence may then differ; solves are analysed again at their next use).
+int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
+{
+    if (!N || !sane_indices(A) || A->m != A->n || A->n != N->f.L.n) return RSP_BAD_INPUT;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(N->guard.m);
+        const CscView Av = view_of(A);
+        if (N->pattern_nnz != Av.nnz() || N->pattern != pattern_hash(Av)) return (int)RSP_BAD_INPUT;
+        if (N->device) {
+            if (!N->device->same_pattern(Av)) return (int)RSP_BAD_INPUT;
+            RSP_HIP(hipDeviceSynchronize());  // solves still in flight read the coefficients that are about to change
+            if (N->device->factor(A->x, tol) == kOk) {
+                N->device->download(N->f);
+                if (N->lower) {
+                    if (N->lower->refresh_host(N->f.L.view()) && N->upper->refresh_host(N->f.U.view())) {
+                        N->lower->refresh_upload();
+                        N->upper->refresh_upload();
+                    } else {
+                        N->lower.reset();
+                        N->upper.reset();
+                    }
+                }
+                return (int)RSP_OK;
+            }
+            N->device.reset();
+        }
+        // the host routine, with the column order of the first factorisation
+        if (N->lower) RSP_HIP(hipDeviceSynchronize());
+        LuFactors f;
+        if (int st = sparse_lu(Av, N->q_factor.empty() ? nullptr : N->q_factor.data(), tol, f)) return st;
+        N->f = std::move(f);
+        N->on_device = false;
+        N->lower.reset();
+        N->upper.reset();
+        N->d_pinv = DeviceBuffer<int64_t>();
+        return (int)RSP_OK;
+    });
+}
+
 // the two triangular handles of a factorisation, built on its first solve (caller holds the guard)
 static int lu_solvers(rsp_lu *N)
 {
     if (N->lower) return RSP_OK;
     std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
+    if (N->device && !N->single_use) {  // a refactorisation may follow: the programmes keep the recipe for new coefficients
+        lo->keep_for_refill();
+        up->keep_for_refill();
+    }
     if (int st = analyze_pair(*lo, N->f.L.view(), RSP_LSOLVE, *up, N->f.U.view(), RSP_USOLVE, N->single_use)) return st;
     N->lower = std::move(lo);
     N->upper = std::move(up);

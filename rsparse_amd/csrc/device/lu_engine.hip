@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
+#include <memory>
+
 namespace rsp {
 namespace dev {
 
@@ -46,23 +49,27 @@ __device__ __forceinline__ void turn()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-constexpr unsigned kLuSpinLimit = 1u << 26;  // polls of a dependency's flag before a wait gives up (tens of seconds)
-
 struct LuControl {
     int next;       // the next column to take
-    int first_bad;  // smallest column whose diagonal failed the pivot rule (INT_MAX: none)
+    int first_bad;  // smallest column whose diagonal failed the pivot rule (INT_MAX: none; -1: a wait gave up)
+    int stuck_k, stuck_j;  // the wait that gave up: column stuck_k on its dependency stuck_j
 };
 
 // persistent: gridDim.x wavefronts (one per workgroup), each with its own zeroed work vector of n doubles (left zeroed);
 // done[k] != 0 once column k of L and U is complete in memory
-__global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64_t n, double tol, LuControl *ctl, int *done)
+__global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64_t n, double tol, LuControl *ctl, int *done, unsigned spin_limit)
 {
+#pragma clang fp contract(off)  // never fused: the reference rounds the product and the difference separately.  (Plain operators under
+                                // this pragma, not __dmul_rn/__dsub_rn: those are inline a * b and a - b from a header compiled with
+                                // contraction allowed, and came out as one v_fma_f64.)
     const int lane = threadIdx.x;
     double *x = work + (int64_t)blockIdx.x * n;
     for (;;) {
-        int k = 0;
-        if (lane == 0) k = atomicAdd(&ctl->next, 1);
-        k = __shfl(k, 0, 64);
+        // the next column, for the whole wavefront.  No `if (lane == 0)` around the atomic: the compiler unswitched this loop on
+        // that (loop-invariant) condition and sent lanes 1..63 round a back edge of their own, reading k = 0 for ever; an add
+        // of 0 from the other lanes leaves the counter alone, and readfirstlane tells the compiler that k is uniform
+        int k = atomicAdd(&ctl->next, lane == 0 ? 1 : 0);
+        k = __builtin_amdgcn_readfirstlane(k);
         if (k >= n) break;  // every wavefront gets here: the counter only grows
         const int ac = M.acol[k];
         for (int64_t e = M.Ap[ac] + lane; e < M.Ap[ac + 1]; e += 64) xstore(x + M.Arow[e], M.Ax[e]);  // x = A(:, q[k])  (lib.rs:2346-2348)
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
             const unsigned long long ready_mask = __ballot(ready);
             const int cnt = min(64, ud - t0);
             for (int s = 0; s < cnt; ++s) {
-                const int j = __shfl(mine, s, 64);
+                const int j = __builtin_amdgcn_readlane(mine, s);  // uniform, and known to be
                 if (!((ready_mask >> s) & 1ull)) {  // column j (< k) is in flight on a wavefront that is running: wait for it
                     // (bounded: were a flag never raised -- a defect -- the wait gives up after seconds, marks the run as failed,
                     // and every other wait sees the mark, so the grid always drains)
@@ -81,7 +88,10 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
                     while (__hip_atomic_load(done + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                         __builtin_amdgcn_s_sleep(2);
                         if ((++spins & 1023u) == 0) {
-                            if (spins >= kLuSpinLimit && lane == 0) atomicMin(&ctl->first_bad, -1);
+                            if (spins >= spin_limit && lane == 0 && atomicMin(&ctl->first_bad, -1) >= 0) {
+                                ctl->stuck_k = k;
+                                ctl->stuck_j = j;
+                            }
                             if (__hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;
                         }
                     }
@@ -90,7 +100,9 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
                 const double xj = xload(x + j);
                 for (int p = M.Lp[j] + 1 + lane; p < M.Lp[j + 1]; p += 64) {
                     const int r = M.Li[p];
-                    xstore(x + r, __dsub_rn(xload(x + r), __dmul_rn(xload(M.Lx + p), xj)));  // two roundings, as in the reference (no fused multiply-add)
+                    const double lx = xload(M.Lx + p);
+                    const double product = lx * xj;  // rounded on its own, as in the reference
+                    xstore(x + r, xload(x + r) - product);
                 }
             }
         }
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
             xstore(x + k, 0.0);
         }
         for (int p = M.Lp[k] + 1 + lane; p < M.Lp[k + 1]; p += 64) {
-            xstore(M.Lx + p, __ddiv_rn(xload(x + M.Li[p]), pivot));  // lib.rs:604
+            xstore(M.Lx + p, xload(x + M.Li[p]) / pivot);  // lib.rs:604 (IEEE division)
             xstore(x + M.Li[p], 0.0);
         }
         turn();  // L(:,k) is in the L2 before the flag is (a failed column raises it too: nobody may wait for ever)
@@ -129,67 +141,124 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
 
 }  // namespace dev
 
-constexpr double kLuMinUpdates = 2e6;  // below this many multiply-subtracts the host routine is done in a few milliseconds
-constexpr int kLuDeclined = 100;  // lu_numeric_device: not applicable or not worth it here -- use sparse_lu
+constexpr double kLuMinUpdates = 1e8;  // below this many multiply-subtracts the host routine finishes as soon as patterns plus device set-up
+constexpr int kLuDeclined = 100;       // lu_numeric_device: not applicable or not worth it here -- use sparse_lu
 
-// kOk: out = the factors (bit-identical to sparse_lu's); kLuDeclined: see above; throws DeviceError.
+// Device half of one factorisation with static pivots: the patterns of A, L and U resident, the values computed by
+// lu_columns.  Kept by the handle, so that a matrix with the SAME pattern and new values is factored again by the kernel
+// alone (rsp_lu_refactor_f64: nothing of the depth-first search is repeated).
+class LuDevice {
+   public:
+    // f: patterns from lu_static_pattern (p, i, pinv); A: the matrix they belong to; q: its column order (nullptr: natural)
+    void setup(const CscView &A, const i64 *q, const LuFactors &f)
+    {
+        n_ = A.n;
+        nnz_ = A.nnz();
+        pattern_ = pattern_hash(A);
+        q_.assign((size_t)n_, 0);
+        for (i64 k = 0; k < n_; ++k) q_[(size_t)k] = q ? q[k] : k;
+        has_q_ = q != nullptr;
+        std::vector<int32_t> arow((size_t)nnz_), acol((size_t)n_), Lp((size_t)n_ + 1), Li(f.L.i.size()), Up((size_t)n_ + 1), Ui(f.U.i.size());
+        for (i64 e = 0; e < nnz_; ++e) arow[(size_t)e] = (int32_t)f.pinv[(size_t)A.i[e]];
+        for (i64 k = 0; k < n_; ++k) acol[(size_t)k] = (int32_t)q_[(size_t)k];
+        for (i64 k = 0; k <= n_; ++k) { Lp[(size_t)k] = (int32_t)f.L.p[(size_t)k]; Up[(size_t)k] = (int32_t)f.U.p[(size_t)k]; }
+        for (size_t e = 0; e < Li.size(); ++e) Li[e] = (int32_t)f.L.i[e];
+        for (size_t e = 0; e < Ui.size(); ++e) Ui[e] = (int32_t)f.U.i[e];
+        dAp_.upload(A.p, (size_t)n_ + 1);
+        dArow_.upload(arow);
+        dAcol_.upload(acol);
+        dLp_.upload(Lp); dLi_.upload(Li); dUp_.upload(Up); dUi_.upload(Ui);
+        dAx_.resize((size_t)nnz_);
+        dLx_.resize(Li.size());
+        dUx_.resize(Ui.size());
+        // one work vector per wavefront in flight: as many as 4 GiB hold, at most 8 per SIMD of the device (all resident at once)
+        hipDeviceProp_t prop;
+        int device = 0;
+        RSP_HIP(hipGetDevice(&device));
+        RSP_HIP(hipGetDeviceProperties(&prop, device));
+        slots_ = std::max<i64>(1, std::min<i64>({(i64)prop.multiProcessorCount * 32, n_, ((i64)4 << 30) / (8 * n_)}));
+        dWork_.resize((size_t)(slots_ * n_));
+        RSP_HIP(hipMemsetAsync(dWork_.get(), 0, (size_t)(slots_ * n_) * sizeof(double), nullptr));  // lu_columns leaves it zeroed
+        dDone_.resize((size_t)n_);
+        dCtl_.resize(1);
+    }
+    // values Ax (host, in the order of the pattern given to setup): runs the factorisation.  kOk, or kLuDeclined when some
+    // column would not have taken its diagonal as pivot (the values on the device are then meaningless).  Synchronises.
+    int factor(const double *Ax, double tol)
+    {
+        dAx_.upload(Ax, (size_t)nnz_);
+        RSP_HIP(hipMemsetAsync(dDone_.get(), 0, (size_t)n_ * sizeof(int), nullptr));
+        const dev::LuControl start{0, INT_MAX, -1, -1};
+        dCtl_.upload(&start, 1);
+        // polls of one dependency's flag before a wait gives up (a poll is about a microsecond: tens of seconds by default)
+        const char *spin_env = getenv("RSP_LU_SPIN_LIMIT");
+        const unsigned spin_limit = spin_env && *spin_env ? (unsigned)strtoul(spin_env, nullptr, 10) : (1u << 25);
+        const dev::LuArrays M{dAp_.get(), dArow_.get(), dAx_.get(), dAcol_.get(), dLp_.get(), dLi_.get(), dLx_.get(), dUp_.get(), dUi_.get(), dUx_.get()};
+        hipLaunchKernelGGL(dev::lu_columns, dim3((unsigned)slots_), dim3(64), 0, nullptr, M, dWork_.get(), n_, tol, dCtl_.get(), dDone_.get(), spin_limit);
+        RSP_HIP(hipGetLastError());
+        dev::LuControl end{};
+        dCtl_.download(&end, 1);  // (synchronises)
+        if (end.first_bad < 0)
+            throw DeviceError("lu_columns: column " + std::to_string(end.stuck_k) + " gave up waiting for column " + std::to_string(end.stuck_j) +
+                              " (next " + std::to_string(end.next) + ")");
+        return end.first_bad != INT_MAX ? kLuDeclined : kOk;
+    }
+    void download(LuFactors &f) const
+    {
+        dLx_.download(f.L.x.data(), f.L.x.size());
+        dUx_.download(f.U.x.data(), f.U.x.size());
+    }
+    bool same_pattern(const CscView &A) const { return A.n == n_ && A.m == n_ && A.nnz() == nnz_ && pattern_hash(A) == pattern_; }
+    const i64 *q() const { return has_q_ ? q_.data() : nullptr; }
+    i64 wavefronts() const { return slots_; }
+
+   private:
+    i64 n_ = 0, nnz_ = 0, slots_ = 0;
+    uint64_t pattern_ = 0;
+    std::vector<i64> q_;
+    bool has_q_ = false;
+    DeviceBuffer<int64_t> dAp_;
+    DeviceBuffer<int32_t> dArow_, dAcol_, dLp_, dLi_, dUp_, dUi_;
+    DeviceBuffer<double> dAx_, dLx_, dUx_, dWork_;
+    DeviceBuffer<int> dDone_;
+    DeviceBuffer<dev::LuControl> dCtl_;
+};
+
+// kOk: out = the factors (bit-identical to sparse_lu's), *keep = the device half when keep != nullptr; kLuDeclined: see above;
+// throws DeviceError.
 // mode: 0 never, 1 always when applicable, anything else: when there is enough numeric work to pay for the device set-up
-int lu_numeric_device(const CscView &A, const i64 *q, double tol, LuFactors &out, int mode)
+int lu_numeric_device(const CscView &A, const i64 *q, double tol, LuFactors &out, int mode, std::unique_ptr<LuDevice> *keep)
 {
     const i64 n = A.n;
     if (mode == 0 || n == 0 || !(tol <= 1.0)) return kLuDeclined;  // (tol > 1 can make the reference refuse a diagonal that is the maximum)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return kLuDeclined;
+    if (A.nnz() >= INT32_MAX) return kLuDeclined;
     std::vector<int32_t> level;
     LuFactors f;
+    const bool trace = getenv("RSP_LU_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     if (!lu_static_pattern(A, q, f, level)) return kLuDeclined;
+    const auto t1 = now();
     // the numeric work the host would do: one update per entry of L(:,j) per dependency j of a column
     double updates = 0;
     for (i64 k = 0; k < n; ++k)
         for (i64 t = f.U.p[(size_t)k]; t + 1 < f.U.p[(size_t)k + 1]; ++t) updates += (double)(f.L.p[(size_t)f.U.i[(size_t)t] + 1] - f.L.p[(size_t)f.U.i[(size_t)t]] - 1);
-    if (mode != 1 && updates < kLuMinUpdates) return kLuDeclined;  // the host finishes sooner than the device set-up costs
-    if (A.nnz() >= INT32_MAX) return kLuDeclined;
-    std::vector<int32_t> arow((size_t)A.nnz()), acol((size_t)n), Lp((size_t)n + 1), Li(f.L.i.size()), Up((size_t)n + 1), Ui(f.U.i.size());
-    for (i64 e = 0; e < A.nnz(); ++e) arow[(size_t)e] = (int32_t)f.pinv[(size_t)A.i[e]];
-    for (i64 k = 0; k < n; ++k) acol[(size_t)k] = (int32_t)(q ? q[k] : k);
-    for (i64 k = 0; k <= n; ++k) { Lp[(size_t)k] = (int32_t)f.L.p[(size_t)k]; Up[(size_t)k] = (int32_t)f.U.p[(size_t)k]; }
-    for (size_t e = 0; e < Li.size(); ++e) Li[e] = (int32_t)f.L.i[e];
-    for (size_t e = 0; e < Ui.size(); ++e) Ui[e] = (int32_t)f.U.i[e];
-    DeviceBuffer<int64_t> dAp;
-    DeviceBuffer<int32_t> dArow, dAcol, dLp, dLi, dUp, dUi;
-    DeviceBuffer<double> dAx, dLx, dUx, dWork;
-    DeviceBuffer<int> dDone;
-    DeviceBuffer<dev::LuControl> dCtl;
-    dAp.upload(A.p, (size_t)n + 1);
-    dArow.upload(arow);
-    dAx.upload(A.x, (size_t)A.nnz());
-    dAcol.upload(acol);
-    dLp.upload(Lp); dLi.upload(Li); dUp.upload(Up); dUi.upload(Ui);
-    dLx.resize(Li.size());
-    dUx.resize(Ui.size());
-    // one work vector per wavefront in flight: as many as 4 GiB hold, at most 8 per SIMD of the device (all resident at once)
-    hipDeviceProp_t prop;
-    int device = 0;
-    RSP_HIP(hipGetDevice(&device));
-    RSP_HIP(hipGetDeviceProperties(&prop, device));
-    const i64 resident = (i64)prop.multiProcessorCount * 32;
-    const i64 slots = std::max<i64>(1, std::min<i64>({resident, n, ((i64)4 << 30) / (8 * n)}));
-    dWork.resize((size_t)(slots * n));
-    RSP_HIP(hipMemsetAsync(dWork.get(), 0, (size_t)(slots * n) * sizeof(double), nullptr));
-    dDone.resize((size_t)n);
-    RSP_HIP(hipMemsetAsync(dDone.get(), 0, (size_t)n * sizeof(int), nullptr));
-    const dev::LuControl start{0, INT_MAX};
-    dCtl.upload(&start, 1);
-    const dev::LuArrays M{dAp.get(), dArow.get(), dAx.get(), dAcol.get(), dLp.get(), dLi.get(), dLx.get(), dUp.get(), dUi.get(), dUx.get()};
-    hipLaunchKernelGGL(dev::lu_columns, dim3((unsigned)slots), dim3(64), 0, nullptr, M, dWork.get(), n, tol, dCtl.get(), dDone.get());
-    RSP_HIP(hipGetLastError());
-    dev::LuControl end{};
-    dCtl.download(&end, 1);  // (synchronises)
-    if (end.first_bad < 0) throw DeviceError("lu_columns: a dependency flag was never raised");
-    if (end.first_bad != INT_MAX) return kLuDeclined;  // some column would not have taken its diagonal: the pivot sequence is not this one
-    dLx.download(f.L.x.data(), f.L.x.size());
-    dUx.download(f.U.x.data(), f.U.x.size());
+    if (mode != 1 && updates < kLuMinUpdates) return kLuDeclined;
+    std::unique_ptr<LuDevice> D(new LuDevice);
+    D->setup(A, q, f);
+    const auto t2 = now();
+    const int st = D->factor(A.x, tol);
+    const auto t3 = now();
+    if (st != kOk) return st;
+    D->download(f);
+    if (trace)
+        fprintf(stderr, "[rsp lu] n %lld updates %.3g: patterns (host) %.1f ms, set-up and upload %.1f ms, lu_columns on %lld wavefronts %.1f ms, download %.1f ms\n",
+                (long long)n, updates, ms(t0, t1), ms(t1, t2), (long long)D->wavefronts(), ms(t2, t3), ms(t3, now()));
     out = std::move(f);
+    if (keep) *keep = std::move(D);
     return kOk;
 }
 

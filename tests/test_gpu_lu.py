@@ -1,0 +1,210 @@
+"""GPU numeric LU (device/lu_engine.hip), through the C ABI (rsp_lu_f64 / rsp_lu_refactor_f64 / rsp_lusol_f64).
+
+rsparse::lu (lib.rs:519-622) pivots by threshold; the GPU path assumes every column keeps its DIAGONAL as pivot, computes
+the values left-looking in the reference's operation order and verifies the assumption column by column.  The bar is
+bit-exactness -- pinv, the patterns of L and U in storage order, and every value -- against the oracle (the C restatement
+of the reference, itself pinned by the reference's fixtures in tests/test_oracle_*.py):
+  * matrices where the diagonal pivots hold (forced onto the GPU): identical bits,
+  * matrices where they do not (a weak diagonal, a structurally missing one, the reference's own lusol_3/lusol_6): the
+    device check fires and the host routine's result -- identical bits again -- is what the caller gets,
+  * BASELINE.json's C4 size (200 000 unknowns) in the default mode: the GPU path is taken and equals the host routine,
+  * refactorisation with new values on the same pattern: identical to a fresh oracle lu, with the resident solve programmes
+    refreshed in place; values that break the pivot rule fall back to the host routine."""
+import numpy as np
+import pytest
+
+import rsparse_amd as rs
+from helpers import load_sprs
+from oracle import pyoracle as orc
+from rsparse_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_bits(N, want):
+    assert N.pinv.tolist() == want["pinv"].tolist()
+    for got, ref in ((N.l, want["L"]), (N.u, want["U"])):
+        assert got.p.tolist() == ref[2].tolist()
+        assert np.array_equal(got.i.astype(np.int64), ref[3])
+        assert np.array_equal(got.x.view(np.int64), ref[4].view(np.int64))
+
+
+def _dominant(name):
+    if name == "band_600":
+        return synth.banded_unsymmetric(600, band=20)
+    if name == "band_3000":
+        return synth.banded_unsymmetric(3000, 5, 10, 1)
+    if name == "band_20000":
+        return synth.banded_unsymmetric(20000, 7, 30, 3)
+    if name == "circuit_500":
+        return synth.circuit_spd(500)
+    if name == "lap2d_64":
+        return synth.laplacian_2d(64)
+    if name == "lap2d_41x29":
+        return synth.laplacian_2d(41, 29)
+    if name == "lap3d_9":
+        return synth.laplacian_3d(9)
+    if name == "randspd_200":
+        return synth.random_sparse(200, 0.02, seed=12, symmetric_pd=True)
+    if name == "one":
+        return (1, 1, np.array([0, 1], np.int64), np.array([0], np.int64), np.array([-2.5]))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["one", "band_600", "band_3000", "band_20000", "circuit_500", "lap2d_64", "lap2d_41x29", "lap3d_9",
+                                  "randspd_200"])
+@pytest.mark.parametrize("order,tol", [(1, 1.0), (-1, 1.0), (0, 0.5), (2, 1e-3)])
+def test_gpu_lu_is_bit_identical_to_the_oracle(name, order, tol, monkeypatch):
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = _dominant(name)
+    st, want = orc.lu(A, order, tol)
+    assert st == orc.OK
+    N = rs.lu(A, rs.sqr(A, order), tol)
+    assert N.on_device, "the diagonal pivots hold for this matrix: the values must come from the GPU"
+    _same_bits(N, want)
+
+
+def _weak_diagonal(n=400):
+    """banded and dominant except ONE diagonal entry far too small: threshold pivoting leaves the diagonal there"""
+    m, nn, p, i, x = synth.banded_unsymmetric(n, 5, 8, 9)
+    x = x.copy()
+    col = n // 2
+    for e in range(p[col], p[col + 1]):
+        if i[e] == col:
+            x[e] = 1e-9
+    return (m, nn, p, i, x)
+
+
+def _missing_diagonal():
+    """a permutation-like matrix: no structural diagonal at all in columns 0 and 1"""
+    return (3, 3, np.array([0, 2, 4, 6], np.int64), np.array([1, 2, 0, 2, 0, 2], np.int64), np.array([2.0, 1.0, 3.0, 0.5, 1.0, 4.0]))
+
+
+@pytest.mark.parametrize("name", ["weak", "missing", "lusol_3.sprs", "lusol_4.sprs", "lusol_6.sprs", "rand_300"])
+@pytest.mark.parametrize("order,tol", [(1, 1.0), (-1, 1.0), (0, 0.5)])
+def test_gpu_lu_hands_over_to_the_host_when_pivots_move(name, order, tol, monkeypatch):
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = {"weak": _weak_diagonal, "missing": _missing_diagonal, "rand_300": lambda: synth.random_sparse(300, 0.02, seed=11)}.get(
+        name, lambda: load_sprs(name))()
+    st, want = orc.lu(A, order, tol)
+    assert st == orc.OK
+    S = rs.sqr(A, order)
+    N = rs.lu(A, S, tol)
+    _same_bits(N, want)  # whichever path produced it
+    q = want["q"]
+    static = bool(np.array_equal(want["pinv"][q], np.arange(A[1])))  # did the reference keep every diagonal?
+    if not static:
+        assert not N.on_device
+    if name == "missing" or (name == "weak" and tol == 1.0):
+        assert not static  # these cases are here to make the device check (or the structural one) fire
+
+
+def test_gpu_lu_modes(monkeypatch):
+    A = synth.banded_unsymmetric(600, band=20)
+    S = rs.sqr(A, 1)
+    monkeypatch.setenv("RSP_LU_GPU", "0")
+    assert not rs.lu(A, S, 1.0).on_device
+    monkeypatch.delenv("RSP_LU_GPU")
+    assert not rs.lu(A, S, 1.0).on_device  # too little work to pay for the device set-up: the default leaves it to the host
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    assert rs.lu(A, S, 1.0).on_device
+    assert not rs.lu(A, S, 1.5).on_device  # tol > 1: the diagonal may lose against itself; host routine
+
+
+def test_gpu_lu_full_size_c4_default_mode_equals_the_host_routine(monkeypatch):
+    """BASELINE.json C4: 200 000 unknowns.  No environment switch: the library itself must pick the GPU here."""
+    A = rs.Sprs.from_tuple(synth.banded_unsymmetric(200000))
+    S = rs.sqr(A, 1)
+    monkeypatch.delenv("RSP_LU_GPU", raising=False)
+    G = rs.lu(A, S, 1.0)
+    assert G.on_device
+    monkeypatch.setenv("RSP_LU_GPU", "0")
+    H = rs.lu(A, S, 1.0)
+    assert not H.on_device
+    assert np.array_equal(G.pinv, H.pinv)
+    for g, h in ((G.l, H.l), (G.u, H.u)):
+        assert np.array_equal(g.p, h.p) and np.array_equal(g.i, h.i) and np.array_equal(g.x.view(np.int64), h.x.view(np.int64))
+    # and the factors solve the system (size-independent check): relative residual of A x = b
+    b = 2.0 * synth.splitmix64(3, A.n) - 1.0
+    x = b.copy()
+    G.solve(x)
+    r = rs.gaxpy(A, x, -b)  # A x - b
+    assert np.linalg.norm(r) / np.linalg.norm(b) <= 1e-10
+
+
+def _revalued(A, seed, scale=0.2):
+    """same pattern, every value moved by up to +-scale of itself (dominance kept)"""
+    m, n, p, i, x = A
+    return (m, n, p, i, x * (1.0 + scale * (2.0 * synth.splitmix64(seed, x.size) - 1.0)))
+
+
+@pytest.mark.parametrize("name,order", [("band_3000", 1), ("lap2d_64", 1), ("circuit_500", 0), ("band_20000", -1)])
+def test_gpu_lu_refactorisation(name, order, monkeypatch):
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = _dominant(name)
+    n = A[1]
+    S = rs.sqr(A, order)
+    N = rs.lu(A, S, 1.0)
+    assert N.on_device
+    B = np.asfortranarray(2.0 * synth.splitmix64(21, n * 64).reshape(64, n).T - 1.0)
+    X = B.copy(order="F")
+    N.solve(X)  # the solve programmes are resident from here on
+    on_device = True
+    for seed in (5, 6):
+        A2 = _revalued(A, seed, 0.01 if name.startswith("lap") else 0.2)  # (a Laplacian is only weakly dominant: 5% already moves pivots)
+        N.refactor(A2, 1.0)
+        st, want = orc.lu(A2, order, 1.0)
+        assert st == orc.OK
+        # the device keeps the handle for as long as the reference keeps every diagonal (circuit_500 loses one at seed 6: the
+        # host routine takes over there, for good)
+        on_device = on_device and bool(np.array_equal(want["pinv"][want["q"]], np.arange(n)))
+        assert N.on_device == on_device
+        _same_bits(N, want)
+        X = B.copy(order="F")
+        N.solve(X)  # through the refreshed programmes
+        for c in (0, 63):
+            st, ref = orc.lusol(A2, B[:, c], order, 1.0)
+            assert st == orc.OK
+            assert np.max(np.abs(X[:, c] - ref)) / np.max(np.abs(ref)) <= 1e-8
+    # another pattern is refused, the handle stays what it was
+    other = synth.banded_unsymmetric(n, 3, 4, 77)
+    if other[2][-1] != A[2][-1] or not np.array_equal(other[3], A[3]):
+        with pytest.raises(rs.DeviceError):
+            N.refactor(other, 1.0)
+        _same_bits(N, want)
+
+
+def test_gpu_lu_refactorisation_that_loses_its_pivots(monkeypatch):
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = synth.banded_unsymmetric(400, 5, 8, 9)
+    W = _weak_diagonal(400)  # the same pattern
+    assert np.array_equal(A[2], W[2]) and np.array_equal(A[3], W[3])
+    S = rs.sqr(A, 1)
+    N = rs.lu(A, S, 1.0)
+    assert N.on_device
+    b = 2.0 * synth.splitmix64(8, 400) - 1.0
+    x = b.copy()
+    N.solve(x)
+    N.refactor(W, 1.0)
+    assert not N.on_device  # the device check fired; the host routine factored W
+    st, want = orc.lu(W, 1, 1.0)
+    assert st == orc.OK
+    _same_bits(N, want)
+    x = b.copy()
+    N.solve(x)
+    st, ref = orc.lusol(W, b, 1, 1.0)
+    assert np.max(np.abs(x - ref)) / np.max(np.abs(ref)) <= 1e-8
+    N.refactor(A, 1.0)  # and a host handle refactors on the host
+    st, want = orc.lu(A, 1, 1.0)
+    _same_bits(N, want)
+
+
+def test_lusol_through_the_gpu_lu(monkeypatch):
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = synth.banded_unsymmetric(3000, 5, 10, 1)
+    b = 2.0 * synth.splitmix64(4, 3000) - 1.0
+    st, want = orc.lusol(A, b, 1, 1.0)
+    assert st == orc.OK
+    got = b.copy()
+    rs.lusol(A, got, 1, 1.0)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= 1e-8

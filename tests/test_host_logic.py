@@ -93,6 +93,36 @@ def test_lu_bit_exact(name, order, tol):
     assert q.tolist() == want["q"].tolist()
 
 
+@pytest.mark.parametrize("name", ["band_600", "circuit_500", "lap2d_24x17", "lap2d_64", "lap3d_9", "randspd_200"])
+@pytest.mark.parametrize("order", [1, -1, 0])
+def test_lu_static_pattern_is_the_pattern_of_the_reference_when_diagonals_pivot(name, order):
+    """Integer half of the GPU numeric LU (host/lu_static.cpp): on matrices whose every column keeps its diagonal as pivot,
+    pinv and the patterns of L and U in storage order equal the oracle's lu (lib.rs:519-622)."""
+    A = MATS[name]
+    st, want = orc.lu(A, order, 1.0)
+    assert st == orc.OK
+    n = A[1]
+    assert np.array_equal(want["pinv"][want["q"]], np.arange(n)), "test matrix must keep its diagonal pivots"
+    N, depth = rs.lu_static_pattern(A, rs.sqr(A, order))
+    assert 1 <= depth <= n
+    assert N.pinv.tolist() == want["pinv"].tolist()
+    for got, ref in ((N.l, want["L"]), (N.u, want["U"])):
+        assert got.p.tolist() == ref[2].tolist()
+        assert got.i.astype(np.int64).tolist() == ref[3].tolist()
+        assert not got.x.any()  # values are the device's business
+
+
+def test_lu_static_pattern_refuses_what_the_device_cannot_do():
+    # no structural diagonal in column 0: there is no static pivot sequence
+    A = (2, 2, np.array([0, 1, 3], np.int64), np.array([1, 0, 1], np.int64), np.array([1.0, 2.0, 3.0]))
+    with pytest.raises(rs.DeviceError):
+        rs.lu_static_pattern(A, rs.sqr(A, -1))
+    # a duplicate entry inside a column (the reference keeps the last value; the device scatters in parallel)
+    D = (2, 2, np.array([0, 3, 4], np.int64), np.array([0, 1, 0, 1], np.int64), np.array([1.0, 2.0, 3.0, 4.0]))
+    with pytest.raises(rs.DeviceError):
+        rs.lu_static_pattern(D, rs.sqr(D, -1))
+
+
 def test_lu_no_pivot_error():
     A = rs.Sprs.from_vec([[1.0, 2.0], [2.0, 4.0]])  # singular
     with pytest.raises(rs.NoPivot):
