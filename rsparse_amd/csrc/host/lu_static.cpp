@@ -7,11 +7,52 @@
 // neighbours visited in storage order) with the pivot of column k known in advance, pinv[q[k]] = k.
 // The device computes the values on these patterns (device/lu_engine.hip) and checks the assumption column by column;
 // when it fails anywhere the caller falls back to sparse_lu.
+//
+// The search costs as many steps as the numeric factorisation costs multiply-subtracts (the reach of column k walks every
+// entry of every column of L it touches) and is what a GPU factorisation spends most of its time in.  It stays
+// sequential: running columns on several threads in ascending order, each waiting for the patterns it needs (the scheme
+// of the device kernel), was measured and is SLOWER than one thread on every test matrix (banded 50 000: 0.73 s on one
+// thread, 1.09 s on eight) -- a column's search dives to the most recent columns first and stalls at once.  What did
+// pay is 32-bit storage of the patterns while they are searched (1.7 times faster than the 64-bit search of host/lu.cpp).
 #include <algorithm>
+#include <memory>
 
+#include "parallel.hpp"
 #include "sparse.hpp"
 
 namespace rsp {
+namespace {
+
+// int32 blocks handed out to one thread; addresses stay put once handed out
+class Arena {
+   public:
+    int32_t *take(size_t count)
+    {
+        if (count > left_) {
+            const size_t size = std::max<size_t>(count, (size_t)1 << 20);
+            blocks_.emplace_back(new int32_t[size]);
+            at_ = blocks_.back().get();
+            left_ = size;
+        }
+        int32_t *p = at_;
+        at_ += count;
+        left_ -= count;
+        return p;
+    }
+
+   private:
+    std::vector<std::unique_ptr<int32_t[]>> blocks_;
+    int32_t *at_ = nullptr;
+    size_t left_ = 0;
+};
+
+struct Column {
+    const int32_t *l = nullptr;  // L(:,k): ORIGINAL row numbers, the pivot row first
+    const int32_t *u = nullptr;  // U(:,k): column numbers (pivot order), the diagonal last
+    int32_t llen = 0, ulen = 0;
+};
+
+}  // namespace
 
 // out.L / out.U: p and i final, x sized and zero; out.pinv; level[k] = 0 for a column that depends on no other, else
 // 1 + the largest level among the columns in U(:,k).  false: some column's diagonal row is not in its reach (a
@@ -20,96 +61,120 @@ bool lu_static_pattern(const CscView &A, const i64 *q, LuFactors &out, std::vect
 {
     const i64 n = A.n;
     if (A.m != n || n >= INT32_MAX) return false;
-    Csc &L = out.L, &U = out.U;
-    L.m = L.n = U.m = U.n = n;
-    L.p.assign(n + 1, 0);
-    U.p.assign(n + 1, 0);
-    L.i.clear();
-    U.i.clear();
-    const i64 guess = 4 * A.nnz() + n;
-    L.i.reserve(guess);
-    U.i.reserve(guess);
-    std::vector<i64> &pinv = out.pinv;
-    pinv.assign(n, -1);
     // the pivot row of every column is known: inverse of q
-    std::vector<i64> col_of_row(n, -1);  // row r is the pivot of column col_of_row[r]
+    std::vector<int32_t> col_of_row((size_t)n, -1);  // row r is the pivot of column col_of_row[r]
     for (i64 k = 0; k < n; ++k) {
         const i64 r = q ? q[k] : k;
-        if (r < 0 || r >= n || col_of_row[r] >= 0) return false;
-        col_of_row[r] = k;
+        if (r < 0 || r >= n || col_of_row[(size_t)r] >= 0) return false;
+        col_of_row[(size_t)r] = (int32_t)k;
     }
-    level.assign(n, 0);
-    std::vector<i64> order(n), stack(n), resume(n), seen(n, -1), dup(n, -1);
+    for (i64 e = 0; e < A.nnz(); ++e)
+        if (A.i[e] < 0 || A.i[e] >= n) return false;
+    level.assign((size_t)n, 0);
+    std::unique_ptr<Column[]> cols(new Column[(size_t)n]);
+    Arena arena;  // (the patterns live in it until they are assembled below)
+    {
+        std::vector<int32_t> order((size_t)n), stack((size_t)n), resume((size_t)n), seen((size_t)n, -1), dup((size_t)n, -1);
+        for (i64 k = 0; k < n; ++k) {
+            const i64 col = q ? q[k] : k;
+            // reach of A(:,col) through the columns of L that exist when column k is factored (columns < k): rows are ORIGINAL
+            // row numbers, as in lu.cpp; row j is pivotal iff its column col_of_row[j] < k, and then that column of L continues
+            // the search
+            i64 top = n;
+            for (i64 e = A.p[col]; e < A.p[col + 1]; ++e) {
+                const int32_t root = (int32_t)A.i[e];
+                if (seen[(size_t)root] == k) continue;  // (reached already, or a duplicate: checked below)
+                i64 depth = 0;
+                stack[0] = root;
+                while (depth >= 0) {
+                    const int32_t j = stack[(size_t)depth];
+                    const int32_t jcol = col_of_row[(size_t)j];
+                    const int32_t *list = nullptr;
+                    int32_t end = 0;
+                    if (jcol < k) {
+                        const Column &c = cols[(size_t)jcol];
+                        list = c.l;
+                        end = c.llen;
+                    }
+                    if (seen[(size_t)j] != k) {
+                        seen[(size_t)j] = (int32_t)k;
+                        resume[(size_t)depth] = 0;
+                    }
+                    bool finished = true;
+                    for (int32_t p = resume[(size_t)depth]; p < end; ++p) {
+                        const int32_t i = list[p];
+                        if (seen[(size_t)i] == k) continue;
+                        resume[(size_t)depth] = p;
+                        stack[(size_t)++depth] = i;
+                        finished = false;
+                        break;
+                    }
+                    if (finished) {
+                        --depth;
+                        order[(size_t)--top] = j;
+                    }
+                }
+            }
+            // duplicate row indices inside the column of A: the reference keeps the LAST value (x[i] = a.x[p] in order); the device
+            // scatters a column's entries in parallel, so such matrices stay on the host
+            bool good = true;
+            for (i64 e = A.p[col]; e < A.p[col + 1] && good; ++e) {
+                if (dup[(size_t)A.i[e]] == k) good = false;
+                dup[(size_t)A.i[e]] = (int32_t)k;
+            }
+            i64 ulen = 1, llen = 1;
+            bool diagonal_reached = false;
+            for (i64 t = top; t < n; ++t) {
+                const int32_t i = order[(size_t)t];
+                if (col_of_row[(size_t)i] < k) ++ulen;
+                else if (i == col) diagonal_reached = true;
+                else ++llen;
+            }
+            if (!good || !diagonal_reached) return false;
+            int32_t *u = arena.take((size_t)ulen), *l = arena.take((size_t)llen);
+            i64 un = 0, ln = 0;
+            int32_t lev = 0;
+            l[ln++] = (int32_t)col;  // L(k,k) first
+            for (i64 t = top; t < n; ++t) {
+                const int32_t i = order[(size_t)t];
+                const int32_t c = col_of_row[(size_t)i];
+                if (c < k) {
+                    u[un++] = c;
+                    lev = std::max(lev, level[(size_t)c] + 1);
+                } else if (i != col) {
+                    l[ln++] = i;
+                }
+            }
+            u[un++] = (int32_t)k;  // U(k,k) last
+            level[(size_t)k] = lev;
+            Column &mine = cols[(size_t)k];
+            mine.l = l;
+            mine.u = u;
+            mine.llen = (int32_t)llen;
+            mine.ulen = (int32_t)ulen;
+        }
+    }
+    // assemble: column pointers, then the indices (row indices of L in pivot order: every row is the pivot of col_of_row[row])
+    Csc &L = out.L, &U = out.U;
+    L.m = L.n = U.m = U.n = n;
+    L.p.assign((size_t)n + 1, 0);
+    U.p.assign((size_t)n + 1, 0);
     for (i64 k = 0; k < n; ++k) {
-        L.p[k] = (i64)L.i.size();
-        U.p[k] = (i64)U.i.size();
-        const i64 col = q ? q[k] : k;
-        // reach of A(:,col) through the columns of L built so far; rows are ORIGINAL row numbers here, as in lu.cpp: row j is
-        // pivotal iff pinv[j] >= 0, and then column pinv[j] of L (stored with original row numbers until the end) continues the search
-        i64 top = n;
-        for (i64 e = A.p[col]; e < A.p[col + 1]; ++e) {
-            const i64 root = A.i[e];
-            if (root < 0 || root >= n) return false;
-            if (seen[root] == k) {
-                // (a second entry with the same row is either a duplicate or already reached: duplicates are checked below)
-                continue;
-            }
-            i64 depth = 0;
-            stack[0] = root;
-            while (depth >= 0) {
-                const i64 j = stack[depth];
-                const i64 jcol = pinv[j];
-                if (seen[j] != k) {
-                    seen[j] = k;
-                    resume[depth] = jcol < 0 ? 0 : L.p[jcol];
-                }
-                const i64 end = jcol < 0 ? 0 : L.p[jcol + 1];  // (jcol < k: final)
-                bool finished = true;
-                for (i64 p = resume[depth]; p < end; ++p) {
-                    const i64 i = L.i[p];
-                    if (seen[i] == k) continue;
-                    resume[depth] = p;
-                    stack[++depth] = i;
-                    finished = false;
-                    break;
-                }
-                if (finished) {
-                    --depth;
-                    order[--top] = j;
-                }
-            }
-        }
-        // duplicate row indices inside the column of A: the reference keeps the LAST value (x[i] = a.x[p] in order); the device
-        // scatters a column's entries in parallel, so such matrices stay on the host
-        for (i64 e = A.p[col]; e < A.p[col + 1]; ++e) {
-            if (dup[A.i[e]] == k) return false;
-            dup[A.i[e]] = k;
-        }
-        bool diagonal_reached = false;
-        for (i64 t = top; t < n; ++t) {
-            const i64 i = order[t];
-            if (pinv[i] >= 0) {
-                U.i.push_back(pinv[i]);
-                level[k] = std::max(level[k], level[pinv[i]] + 1);
-            } else if (i == col) {
-                diagonal_reached = true;
-            }
-        }
-        if (!diagonal_reached) return false;
-        U.i.push_back(k);  // U(k,k) last
-        pinv[col] = k;
-        L.i.push_back(col);  // L(k,k) first
-        for (i64 t = top; t < n; ++t) {
-            const i64 i = order[t];
-            if (pinv[i] < 0) L.i.push_back(i);
-        }
-        L.p[k + 1] = (i64)L.i.size();
-        if ((i64)L.i.size() >= INT32_MAX || (i64)U.i.size() >= INT32_MAX) return false;
+        L.p[(size_t)k + 1] = L.p[(size_t)k] + cols[(size_t)k].llen;
+        U.p[(size_t)k + 1] = U.p[(size_t)k] + cols[(size_t)k].ulen;
     }
-    L.p[n] = (i64)L.i.size();
-    U.p[n] = (i64)U.i.size();
-    // every row became a pivot (q is a permutation); row indices of L in pivot order
-    for (auto &r : L.i) r = pinv[r];
+    if (L.p[(size_t)n] >= INT32_MAX || U.p[(size_t)n] >= INT32_MAX) return false;
+    L.i.resize((size_t)L.p[(size_t)n]);
+    U.i.resize((size_t)U.p[(size_t)n]);
+    parallel_ranges(n, 4096, [&](i64 k0, i64 k1) {
+        for (i64 k = k0; k < k1; ++k) {
+            const Column &c = cols[(size_t)k];
+            i64 *li = L.i.data() + L.p[(size_t)k], *ui = U.i.data() + U.p[(size_t)k];
+            for (int32_t t = 0; t < c.llen; ++t) li[t] = col_of_row[(size_t)c.l[t]];
+            for (int32_t t = 0; t < c.ulen; ++t) ui[t] = c.u[t];
+        }
+    });
+    out.pinv.assign(col_of_row.begin(), col_of_row.end());
     L.x.assign(L.i.size(), 0.0);
     U.x.assign(U.i.size(), 0.0);
     return true;
