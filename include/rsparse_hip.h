@@ -252,11 +252,12 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
 /* ---- LU ---------------------------------------------------------------------------------------
  * rsparse::lu (src/lib.rs:519-622): left-looking LU with threshold partial pivoting.  The values are computed on the GPU
  * when every column keeps its DIAGONAL as pivot under the reference's rule (|diag| >= tol * max|x|, lib.rs:585-589) -- the
- * patterns then follow from integer work on the host, the columns run by dependency level on the device, every column
- * checks the rule, and the factors are bit-identical to the reference's.  Any column that breaks the rule, a matrix
- * with a structurally missing diagonal, or dependency levels too narrow to pay for their launches send the whole
- * factorisation to the host routine instead (the reference's algorithm, sequential).  RSP_LU_GPU=0 forces the host,
- * =1 the GPU whenever the static pivots hold.  rsparse::lusol (src/lib.rs:672-683) then solves with L and U on the GPU. */
+ * patterns then follow from integer work on the host, the columns run on the device in one persistent launch (one
+ * wavefront per column, in the reference's order of operations), every column checks the rule, and the factors are
+ * bit-identical to the reference's, values included.  Any column that breaks the rule, a matrix with a structurally missing
+ * diagonal or duplicate entries in a column, tol > 1, or too little work to pay for the device set-up (< 1e8
+ * multiply-subtracts) send the whole factorisation to the host routine instead (the reference's algorithm, sequential; the
+ * same bits).  RSP_LU_GPU=0 forces the host, =1 the GPU whenever the static pivots apply.  rsparse::lusol (src/lib.rs:672-683) then solves with L and U on the GPU. */
 typedef struct rsp_lu rsp_lu;
 int rsp_lu_f64(const rsp_csc_f64 *A, const rsp_symb *S, double tol, rsp_lu **N);
 int rsp_lu_L(const rsp_lu *N, rsp_csc_f64 *L); /* borrowed views, valid until rsp_lu_free */
@@ -266,14 +267,14 @@ const int64_t *rsp_lu_pinv(const rsp_lu *N);   /* n entries */
  * rsparse::lu produces when every column pivots on its diagonal, values all zero; *nlevels = depth of the column dependency
  * levels.  RSP_BAD_INPUT when a diagonal entry is structurally missing (no static pivot sequence exists). */
 int rsp_lu_static_pattern_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_lu **N, int64_t *nlevels);
-int rsp_lu_on_device(const rsp_lu *N);
+int rsp_lu_on_device(const rsp_lu *N); /* 1: the values came from the GPU numeric LU, 0: from the host routine */
 /* New values on the pattern the handle was made with: N becomes the factorisation of A (same p and i as the matrix given to
  * rsp_lu_f64, RSP_BAD_INPUT otherwise; the column order of that call is kept).  No counterpart in the reference, which calls
  * lu again (lib.rs:519); the result is what that call would give, bit for bit.  When N came from the GPU numeric LU the
  * kernel alone runs again -- no depth-first search, no new analysis, resident solve programmes get the new coefficients --
  * as long as every column still keeps its diagonal as pivot; otherwise the host routine factors A (the pivot sequence may
  * change; solves are analysed again at their next use).  Not concurrent with solves on the same handle. */
-int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol);         /* 1: the values came from the GPU numeric LU, 0: from the host routine */
+int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol);
 /* b <- A^-1 b for nrhs host column-major right-hand sides (ipvec, lsolve, usolve, ipvec: src/lib.rs:678-681) */
 int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs);
 /* the same for a device-resident block in either rsp_layout, asynchronously on `stream`: both permutations run on the
