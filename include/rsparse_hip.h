@@ -236,7 +236,10 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
  * of patterns kept (default 2, 0 switches the cache off), RSP_ANALYSIS_CACHE_MB = device memory they may hold (default
  * 16384); least recently used entries leave first.  rsp_cache_stats: out[0..6] = hits, misses, entries, estimated device
  * bytes, background analyses in flight, inserted, evicted.  rsp_cache_clear waits for the background analyses and frees
- * every cached handle (call it before the process ends if device memory must be returned in an orderly way). */
+ * every cached handle (call it before the process ends if device memory must be returned in an orderly way).
+ * rsp_lusol_f64 shares the cache (and its counters): a call whose factorisation ran on the device (diagonal pivots) leaves
+ * that factorisation's device half behind, a later call on the same pattern is rsp_lu_refactor_f64 + a solve; an entry
+ * whose new values no longer keep their diagonal pivots is factored by the host routine and leaves the cache. */
 int rsp_cache_stats(int64_t *out);
 int rsp_cache_clear(void);
 /* cholsol over `nsys` systems that share ONE pattern (A->p, A->i; A->x is ignored) and differ in their values:

@@ -867,6 +867,7 @@ void rsp_chol_free(rsp_chol *F) { delete F; }
 extern "C++" {
 namespace {
 struct CholCacheEntry {
+    int kind = 0;  // 0: cholsol (S + F), 1: lusol (S + N)
     uint64_t hash = 0;
     int device = 0;
     int8_t order = 0;
@@ -874,7 +875,8 @@ struct CholCacheEntry {
     std::vector<int64_t> p, i;  // the pattern itself: a hit is verified entry by entry
     std::unique_ptr<rsp_symb> S;
     std::unique_ptr<rsp_chol> F;
-    int64_t bytes = 0;  // estimate of the device memory behind F
+    std::unique_ptr<rsp_lu> N;
+    int64_t bytes = 0;  // estimate of the device memory behind F / N
     uint64_t stamp = 0;
 };
 struct CholCache {
@@ -891,6 +893,7 @@ struct CholCache {
         // the process is ending: the HIP runtime may already be gone, the handles' device memory goes with the process
         for (auto &e : entries) {
             (void)e->F.release();
+            (void)e->N.release();
             (void)e->S.release();
         }
     }
@@ -1032,7 +1035,7 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
             std::lock_guard<std::mutex> lock(C.m);
             for (size_t k = 0; k < C.entries.size(); ++k) {
                 CholCacheEntry &e = *C.entries[k];
-                if (e.hash == hash && e.device == device && e.order == order && e.n == A->n && e.nnz == A->p[A->n]) {
+                if (e.kind == 0 && e.hash == hash && e.device == device && e.order == order && e.n == A->n && e.nnz == A->p[A->n]) {
                     hit = std::move(C.entries[k]);  // out of the cache while this call uses it
                     C.entries.erase(C.entries.begin() + (long)k);
                     break;
@@ -1510,15 +1513,164 @@ int rsp_qrsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     return st;
 }
 
+// background job after a lusol call whose factorisation ran on the device: the handle becomes a multi-use one (blocked solve
+// programmes with their refill recipes, resident after one solve of a zero vector) and enters the analysis cache
+extern "C++" {
+namespace {
+void lu_cache_prepare(std::unique_ptr<CholCacheEntry> e)
+{
+    CholCache &C = chol_cache();
+    const uint64_t hash = e->hash;
+    bool ok = false;
+    try {
+        if (hipSetDevice(e->device) == hipSuccess && e->N->device) {
+            rsp_lu *N = e->N.get();
+            {
+                std::lock_guard<std::mutex> lock(N->guard.m);
+                RSP_HIP(hipDeviceSynchronize());
+                N->single_use = false;
+                N->lower.reset();
+                N->upper.reset();
+            }
+            std::vector<double> zero((size_t)e->n, 0.0);
+            ok = rsp_lu_solve_f64(N, e->S.get(), zero.data(), e->n, 1) == RSP_OK;
+            e->bytes = (int64_t)(N->f.L.i.size() + N->f.U.i.size()) * 40 + N->device->device_bytes();
+        }
+    } catch (...) {
+        ok = false;
+    }
+    std::vector<std::unique_ptr<CholCacheEntry>> dead;
+    {
+        std::lock_guard<std::mutex> lock(C.m);
+        C.pending.erase(std::remove(C.pending.begin(), C.pending.end(), hash), C.pending.end());
+        if (ok && e->bytes <= chol_cache_budget() && chol_cache_capacity() > 0) {
+            e->stamp = ++C.clock;
+            C.entries.push_back(std::move(e));
+            C.inserted++;
+            dead = chol_cache_trim(C, chol_cache_capacity(), chol_cache_budget());
+        }
+    }
+    dead.clear();
+    e.reset();
+}
+}  // namespace
+}  // extern "C++"
+
+// rsparse::lusol (lib.rs:672-683).  Like rsp_cholsol_f64 it keeps what a call on the same pattern can reuse -- here only when
+// the factorisation ran on the device (static diagonal pivots): the patterns of L and U then depend on the pattern of A alone,
+// so a later call with the same (device, n, order, pattern) is rsp_lu_refactor_f64 (the kernel alone, the pivot rule checked
+// again with this call's tol) + a solve through the resident programmes.  A hit whose values no longer keep their diagonal
+// pivots is factored by the host routine, as any call would be, and its entry leaves the cache.
 int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol)
 {
     if (!sane_indices(A) || !b || A->m != A->n) return RSP_BAD_INPUT;
+    const int64_t capacity = chol_cache_capacity();
+    uint64_t hash = 0;
+    int device = 0;
+    bool may_insert = false;
+    if (capacity > 0 && A->n > 0) {
+        int st = guarded([&] {
+            if (int rd = require_device()) return rd;
+            RSP_HIP(hipGetDevice(&device));
+            return (int)RSP_OK;
+        });
+        if (st != RSP_OK) return st;
+        hash = pattern_hash(view_of(A));
+        CholCache &C = chol_cache();
+        std::unique_ptr<CholCacheEntry> hit;
+        {
+            std::lock_guard<std::mutex> lock(C.m);
+            for (size_t k = 0; k < C.entries.size(); ++k) {
+                CholCacheEntry &e = *C.entries[k];
+                if (e.kind == 1 && e.hash == hash && e.device == device && e.order == order && e.n == A->n && e.nnz == A->p[A->n]) {
+                    hit = std::move(C.entries[k]);  // out of the cache while this call uses it
+                    C.entries.erase(C.entries.begin() + (long)k);
+                    break;
+                }
+            }
+        }
+        if (hit && !same_pattern(*hit, A)) {  // a hash collision: not this pattern, back it goes
+            std::lock_guard<std::mutex> lock(C.m);
+            C.entries.push_back(std::move(hit));
+            hit.reset();
+        }
+        if (hit) {
+            st = rsp_lu_refactor_f64(hit->N.get(), A, tol);
+            if (st == RSP_OK) st = rsp_lu_solve_f64(hit->N.get(), hit->S.get(), b, A->n, 1);
+            std::vector<std::unique_ptr<CholCacheEntry>> dead;
+            {
+                std::lock_guard<std::mutex> lock(C.m);
+                C.hits++;
+                if (st == RSP_OK && hit->N->device) {
+                    hit->stamp = ++C.clock;
+                    C.entries.push_back(std::move(hit));
+                    dead = chol_cache_trim(C, capacity, chol_cache_budget());
+                } else {
+                    C.evicted++;
+                }
+            }
+            dead.clear();
+            hit.reset();  // (an entry that went to the host routine is no better than a fresh call)
+            return st;
+        }
+        {
+            std::lock_guard<std::mutex> lock(C.m);
+            C.misses++;
+            may_insert = std::find(C.pending.begin(), C.pending.end(), hash) == C.pending.end() && C.pending.size() < 2;
+        }
+    }
     rsp_symb *S = nullptr;
     rsp_lu *N = nullptr;
     int st = rsp_sqr_lu(A, order, &S);               // ordering (host)
-    if (st == RSP_OK) st = rsp_lu_f64(A, S, tol, &N);  // numeric LU (host, pivot sequence bit-exact)
+    if (st == RSP_OK) st = rsp_lu_f64(A, S, tol, &N);  // numeric LU: GPU when the diagonal pivots hold, else host; same bits
     if (st == RSP_OK) N->single_use = true;
     if (st == RSP_OK) st = rsp_lu_solve_f64(N, S, b, A->n, 1);  // lsolve + usolve (GPU)
+    if (st == RSP_OK && may_insert && N->device) {
+        // keep the factorisation's device half and its patterns for the next call on this pattern
+        CholCache &C = chol_cache();
+        std::unique_ptr<CholCacheEntry> e;
+        bool claimed = false;
+        try {
+            e.reset(new CholCacheEntry);
+            e->kind = 1;
+            e->hash = hash;
+            e->device = device;
+            e->order = order;
+            e->n = A->n;
+            e->nnz = A->p[A->n];
+            e->p.assign(A->p, A->p + A->n + 1);
+            e->i.assign(reinterpret_cast<const int64_t *>(A->i), reinterpret_cast<const int64_t *>(A->i) + e->nnz);
+            std::lock_guard<std::mutex> lock(C.m);
+            if (std::find(C.pending.begin(), C.pending.end(), hash) == C.pending.end()) {
+                C.pending.push_back(hash);
+                claimed = true;
+            }
+        } catch (...) {
+            claimed = false;
+        }
+        if (claimed) {
+            e->S.reset(S);
+            e->N.reset(N);
+            CholCacheEntry *raw = e.release();
+            std::thread worker;
+            try {
+                worker = std::thread([raw] { lu_cache_prepare(std::unique_ptr<CholCacheEntry>(raw)); });
+            } catch (...) {  // no thread: the entry is dropped (with S and N), the pattern is free to be claimed again
+                delete raw;
+                std::lock_guard<std::mutex> lock(C.m);
+                C.pending.erase(std::remove(C.pending.begin(), C.pending.end(), hash), C.pending.end());
+                return st;
+            }
+            std::lock_guard<std::mutex> lock(C.m);
+            C.workers.push_back(std::move(worker));
+            if (C.workers.size() > 4) {  // the oldest job has long finished (at most two run at a time): collect it
+                std::thread old = std::move(C.workers.front());
+                C.workers.erase(C.workers.begin());
+                if (old.joinable()) old.join();
+            }
+            return st;  // S and N belong to the cache now
+        }
+    }
     rsp_lu_free(N);
     rsp_symb_free(S);
     return st;

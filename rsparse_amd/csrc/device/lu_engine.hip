@@ -211,6 +211,11 @@ class LuDevice {
     bool same_pattern(const CscView &A) const { return A.n == n_ && A.m == n_ && A.nnz() == nnz_ && pattern_hash(A) == pattern_; }
     const i64 *q() const { return has_q_ ? q_.data() : nullptr; }
     i64 wavefronts() const { return slots_; }
+    i64 device_bytes() const
+    {
+        return (i64)(dAp_.bytes() + dArow_.bytes() + dAcol_.bytes() + dLp_.bytes() + dLi_.bytes() + dUp_.bytes() + dUi_.bytes() + dAx_.bytes() +
+                     dLx_.bytes() + dUx_.bytes() + dWork_.bytes() + dDone_.bytes());
+    }
 
    private:
     i64 n_ = 0, nnz_ = 0, slots_ = 0;

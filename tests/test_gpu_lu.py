@@ -208,3 +208,84 @@ def test_lusol_through_the_gpu_lu(monkeypatch):
     got = b.copy()
     rs.lusol(A, got, 1, 1.0)
     assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= 1e-8
+
+
+def _wait_for_cache():
+    import time
+    t0 = time.time()
+    while rs.cache_stats()["pending"] and time.time() - t0 < 120:
+        time.sleep(0.01)
+    assert not rs.cache_stats()["pending"]
+
+
+def test_lusol_analysis_cache(monkeypatch):
+    """rsp_lusol_f64 keeps the device half of a factorisation per pattern: the same call again with new values is a
+    refactorisation + solve; parity with the oracle's lusol on every call, hit or miss."""
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    rs.cache_clear()
+    A = synth.banded_unsymmetric(20000, 7, 30, 3)
+    n = A[1]
+
+    def check(M, seed, order=1, tol=1.0):
+        b = 2.0 * synth.splitmix64(seed, n) - 1.0
+        st, want = orc.lusol(M, b, order, tol)
+        assert st == orc.OK
+        got = b.copy()
+        rs.lusol(M, got, order, tol)
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= 1e-8
+
+    s0 = rs.cache_stats()
+    check(A, 1)  # a miss; its factorisation moves into the cache in the background
+    _wait_for_cache()
+    s1 = rs.cache_stats()
+    assert s1["misses"] == s0["misses"] + 1 and s1["entries"] == 1
+    check(_revalued(A, 5), 2)  # values only: a hit
+    check(_revalued(A, 6), 3)
+    s2 = rs.cache_stats()
+    assert s2["hits"] == s1["hits"] + 2 and s2["entries"] == 1
+    check(A, 4, order=0)  # another ordering is another analysis
+    _wait_for_cache()
+    s3 = rs.cache_stats()
+    assert s3["misses"] == s2["misses"] + 1 and s3["entries"] == 2
+    # one index moved: another pattern
+    m, nn, p, i, x = A
+    i2 = i.copy()
+    col = n // 3
+    rows = set(i[p[col]:p[col + 1]].tolist())
+    free = next(r for r in range(col + 1, n) if r not in rows)
+    e = p[col + 1] - 1
+    if i2[e] == col:
+        e -= 1
+    i2[e] = free
+    order_in_col = np.argsort(i2[p[col]:p[col + 1]], kind="stable")
+    x2 = x.copy()
+    i2[p[col]:p[col + 1]] = i2[p[col]:p[col + 1]][order_in_col]
+    x2[p[col]:p[col + 1]] = x[p[col]:p[col + 1]][order_in_col]
+    check((m, nn, p, i2, x2), 5)
+    _wait_for_cache()
+    s4 = rs.cache_stats()
+    assert s4["misses"] == s3["misses"] + 1 and s4["hits"] == s3["hits"]
+    rs.cache_clear()
+    assert rs.cache_stats()["entries"] == 0
+
+
+def test_lusol_cache_entry_leaves_when_its_pivots_move(monkeypatch):
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    rs.cache_clear()
+    A = synth.banded_unsymmetric(400, 5, 8, 9)
+    W = _weak_diagonal(400)
+    b = 2.0 * synth.splitmix64(8, 400) - 1.0
+    x = b.copy(); rs.lusol(A, x, 1, 1.0)
+    _wait_for_cache()
+    assert rs.cache_stats()["entries"] == 1
+    st, want = orc.lusol(W, b, 1, 1.0)
+    assert st == orc.OK
+    x = b.copy(); rs.lusol(W, x, 1, 1.0)  # a hit whose device check fires: host routine, same answer, entry gone
+    assert np.max(np.abs(x - want)) / np.max(np.abs(want)) <= 1e-8
+    assert rs.cache_stats()["entries"] == 0
+    # and with the cache switched off nothing is kept
+    monkeypatch.setenv("RSP_ANALYSIS_CACHE", "0")
+    x = b.copy(); rs.lusol(A, x, 1, 1.0)
+    _wait_for_cache()
+    assert rs.cache_stats()["entries"] == 0
+    rs.cache_clear()

@@ -92,6 +92,21 @@ def c4(n):
     t0 = time.time(); N.solve(x); out["first_solve_s_incl_tri_analysis"] = round(time.time() - t0, 2)
     r = spmv(A, x) - b
     out["residual_rel"] = float(np.linalg.norm(r) / np.linalg.norm(b))
+    # the one-shot lusol (lib.rs:672) and the same call again on the pattern the library has kept (analysis cache)
+    rs.cache_clear()
+    xs = b.copy()
+    t0 = time.time(); rs.lusol(A, xs, 1, 1.0); out["lusol_one_shot_s"] = round(time.time() - t0, 2)
+    t0 = time.time()
+    while rs.cache_stats()["pending"] and time.time() - t0 < 300:
+        time.sleep(0.01)
+    out["lusol_cache_fill_wait_s"] = round(time.time() - t0, 2)
+    for key in ("lusol_cached_first_hit_s", "lusol_cached_s"):
+        xs = b.copy()
+        t0 = time.time(); rs.lusol(A2, xs, 1, 1.0); out[key] = round(time.time() - t0, 3)
+    r2 = spmv(A2, xs) - b
+    out["lusol_cached_residual_rel"] = float(np.linalg.norm(r2) / np.linalg.norm(b))
+    out["cache"] = rs.cache_stats()
+    rs.cache_clear()
     lo, up = rs.TriHandle(L, 0), rs.TriHandle(U, 2)
     for k in (1, 256):
         ms = timed_pair(lo, up, n, k)
