@@ -37,9 +37,10 @@ struct LuArrays {
     double *Ux;
 };
 
-// The work vector is read and written by different lanes of one wavefront in turns, and the factor's values by different
-// wavefronts: those accesses go to the L2 (agent-scope atomics: no stale line in a compute unit's L1), and turn() waits until
-// the wavefront's earlier loads and stores have completed there before the next turn issues its own.
+// The factor's values are written by one wavefront and read by others, anywhere on the chip: those accesses are agent-scope
+// atomics (they go to the L2 and beyond, no stale line in a compute unit's L1 or another XCD's L2).  The work vector belongs to
+// ONE wavefront, whose lanes read and write it in turns: plain loads and stores (one compute unit's L1 is coherent for its own
+// accesses), and turn() -- a compiler fence plus s_waitcnt vmcnt(0) -- keeps a turn's accesses behind the previous turn's.
 __device__ __forceinline__ double xload(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void xstore(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void turn()
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= n) break;  // every wavefront gets here: the counter only grows
         const int ac = M.acol[k];
-        for (int64_t e = M.Ap[ac] + lane; e < M.Ap[ac + 1]; e += 64) xstore(x + M.Arow[e], M.Ax[e]);  // x = A(:, q[k])  (lib.rs:2346-2348)
+        for (int64_t e = M.Ap[ac] + lane; e < M.Ap[ac + 1]; e += 64) x[M.Arow[e]] = M.Ax[e];  // x = A(:, q[k])  (lib.rs:2346-2348)
         const int ub = M.Up[k], ud = M.Up[k + 1] - 1;  // U(:,k): dependencies [ub, ud), the diagonal at ud
         for (int t0 = ub; t0 < ud; t0 += 64) {         // x = L \ x over the reach, in reach order (lib.rs:2350-2362)
             const int mine = t0 + lane < ud ? M.Ui[t0 + lane] : -1;
@@ -97,22 +98,22 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
                     }
                 }
                 turn();
-                const double xj = xload(x + j);
+                const double xj = x[j];
                 for (int p = M.Lp[j] + 1 + lane; p < M.Lp[j + 1]; p += 64) {
                     const int r = M.Li[p];
                     const double lx = xload(M.Lx + p);
                     const double product = lx * xj;  // rounded on its own, as in the reference
-                    xstore(x + r, xload(x + r) - product);
+                    x[r] = x[r] - product;
                 }
             }
         }
         turn();
-        const double pivot = xload(x + k);
+        const double pivot = x[k];
         // the pivot rule (lib.rs:566-589): the largest |x| among the rows that are not pivotal yet -- the rows of L(:,k), diagonal
         // included -- must be positive, and the diagonal within tol of it
         double best = fabs(pivot);
         for (int p = M.Lp[k] + 1 + lane; p < M.Lp[k + 1]; p += 64) {
-            const double a = fabs(xload(x + M.Li[p]));
+            const double a = fabs(x[M.Li[p]]);
             best = a > best ? a : best;
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -122,17 +123,17 @@ __global__ __launch_bounds__(64) void lu_columns(LuArrays M, double *work, int64
         const bool ok = best > 0.0 && fabs(pivot) >= best * tol;  // (a NaN anywhere fails one of the two)
         if (!ok && lane == 0) atomicMin(&ctl->first_bad, k);
         for (int t = ub + lane; t < ud; t += 64) {
-            M.Ux[t] = xload(x + M.Ui[t]);
-            xstore(x + M.Ui[t], 0.0);  // the vector goes back to zeros for the next column that uses it (lib.rs:607)
+            M.Ux[t] = x[M.Ui[t]];
+            x[M.Ui[t]] = 0.0;  // the vector goes back to zeros for the next column that uses it (lib.rs:607)
         }
         if (lane == 0) {
             M.Ux[ud] = pivot;                // U(k,k) last (lib.rs:593-595)
             xstore(M.Lx + M.Lp[k], 1.0);     // L(k,k) = 1 first (lib.rs:597-599)
-            xstore(x + k, 0.0);
+            x[k] = 0.0;
         }
         for (int p = M.Lp[k] + 1 + lane; p < M.Lp[k + 1]; p += 64) {
-            xstore(M.Lx + p, xload(x + M.Li[p]) / pivot);  // lib.rs:604 (IEEE division)
-            xstore(x + M.Li[p], 0.0);
+            xstore(M.Lx + p, x[M.Li[p]] / pivot);  // lib.rs:604 (IEEE division)
+            x[M.Li[p]] = 0.0;
         }
         turn();  // L(:,k) is in the L2 before the flag is (a failed column raises it too: nobody may wait for ever)
         if (lane == 0) __hip_atomic_store(done + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
