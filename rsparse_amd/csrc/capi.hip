@@ -947,8 +947,10 @@ void chol_cache_analyse(std::unique_ptr<CholCacheEntry> e)
     try {
         if (hipSetDevice(e->device) == hipSuccess) {
             CscView A{e->n, e->n, e->p.data(), e->i.data(), nullptr};
-            e->S.reset(new rsp_symb);
-            e->S->s = symbolic_cholesky(A, e->order);
+            if (!e->S) {  // (a call that missed hands its own ordering and symbolic analysis over)
+                e->S.reset(new rsp_symb);
+                e->S->s = symbolic_cholesky(A, e->order);
+            }
             e->F.reset(new rsp_chol);
             ok = e->F->f.analyze(A, e->S->s, false) == kOk;
             if (ok) e->F->f.finish_analysis();  // the solve programmes are emitted too: the first hit finds everything ready
@@ -1070,30 +1072,6 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
             if (spawn) C.pending.push_back(hash);
         }
     }
-    std::thread worker;
-    if (spawn) {
-        // the pattern is copied (the caller's arrays are only borrowed) and analysed beside this call's own work
-        std::unique_ptr<CholCacheEntry> e(new CholCacheEntry);
-        e->hash = hash;
-        e->device = device;
-        e->order = order;
-        e->n = A->n;
-        e->nnz = A->p[A->n];
-        bool copied = true;
-        try {
-            e->p.assign(A->p, A->p + A->n + 1);
-            e->i.assign(reinterpret_cast<const int64_t *>(A->i), reinterpret_cast<const int64_t *>(A->i) + e->nnz);
-            CholCacheEntry *raw = e.release();
-            worker = std::thread([raw] { chol_cache_analyse(std::unique_ptr<CholCacheEntry>(raw)); });
-        } catch (...) {
-            copied = false;
-        }
-        if (!copied) {
-            std::lock_guard<std::mutex> lock(chol_cache().m);
-            auto &pend = chol_cache().pending;
-            pend.erase(std::remove(pend.begin(), pend.end(), hash), pend.end());
-        }
-    }
     rsp_symb *S = nullptr;
     rsp_chol *F = nullptr;
     int st = rsp_schol(A, order, &S);                    // ordering and symbolic analysis (host)
@@ -1104,6 +1082,48 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     if (st == RSP_OK) st = rsp_chol_solve_f64(F, b, A->n, 1);  // P, lsolve, ltsolve, P' (GPU)
     const double t3 = clock();
     rsp_chol_free(F);
+    std::thread worker;
+    if (spawn && st < 0) {  // bad input or a device failure: nothing worth analysing again
+        std::lock_guard<std::mutex> lock(chol_cache().m);
+        auto &pend = chol_cache().pending;
+        pend.erase(std::remove(pend.begin(), pend.end(), hash), pend.end());
+        spawn = false;
+    }
+    if (spawn) {
+        // AFTER this call's own work (the two would share the host's cores: started first, the background analysis made the call
+        // itself 10 % slower): the pattern is copied (the caller's arrays are only borrowed), this call's ordering and symbolic
+        // analysis go along, and a thread of the library builds the multi-use analysis while the caller goes on
+        std::unique_ptr<CholCacheEntry> e;
+        bool started = false;
+        try {
+            e.reset(new CholCacheEntry);
+            e->hash = hash;
+            e->device = device;
+            e->order = order;
+            e->n = A->n;
+            e->nnz = A->p[A->n];
+            e->p.assign(A->p, A->p + A->n + 1);
+            e->i.assign(reinterpret_cast<const int64_t *>(A->i), reinterpret_cast<const int64_t *>(A->i) + e->nnz);
+            if (S) {
+                e->S.reset(S);
+                S = nullptr;
+            }
+            CholCacheEntry *raw = e.release();
+            try {
+                worker = std::thread([raw] { chol_cache_analyse(std::unique_ptr<CholCacheEntry>(raw)); });
+                started = true;
+            } catch (...) {
+                delete raw;
+            }
+        } catch (...) {
+            started = false;
+        }
+        if (!started) {
+            std::lock_guard<std::mutex> lock(chol_cache().m);
+            auto &pend = chol_cache().pending;
+            pend.erase(std::remove(pend.begin(), pend.end(), hash), pend.end());
+        }
+    }
     rsp_symb_free(S);
     if (worker.joinable()) {
         std::lock_guard<std::mutex> lock(chol_cache().m);
