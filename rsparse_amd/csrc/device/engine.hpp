@@ -246,7 +246,9 @@ class TriSolver {
         DeviceBuffer<int32_t> map, coef_src, grp_first, grp_row, chain_pos, chain_code;
         DeviceBuffer<BlockProgram::Refill::Tri16> tri16;
         DeviceBuffer<char> chains;  // dev::ChainDesc
-        DeviceBuffer<double> pool, mpool;
+        DeviceBuffer<double> pool, mpool, tpool;  // chain inverses, the chains' triangles, scratch of the blocked inverse
+        DeviceBuffer<char> tiles1, tiles2;        // dev::ChainTile lists of the blocked inverse: T = C Z11 and Z21 = -Z22 T per level
+        std::vector<std::pair<i64, i64>> tile_levels;  // (first, count) of each level in both lists
         i64 ncoef = 0, ngroups = 0, ntri = 0, nchain_entries = 0, pool_size = 0;
         int nchains = 0, ntiles = 0;
         int32_t split = 0, nnz = 0;

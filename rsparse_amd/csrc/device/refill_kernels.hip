@@ -104,8 +104,9 @@ struct ChainDesc {
 // same address in every lane), then the block's own 64 x 64 triangle is solved in registers.  (The first version, one
 // row and one term at a time, paid a memory round trip per term: 136 ms for the chains of the C2 factor, 34 ms with
 // eight terms in flight.)
+// diag_only: only the tile's own 64 x 64 diagonal block is inverted (the blocked inverse below builds the rest from products).
 __global__ __launch_bounds__(64) void chain_invert(const double *__restrict__ Mpool, double *__restrict__ pool, const ChainDesc *__restrict__ chains,
-                                                   int nchains)
+                                                   int nchains, int diag_only)
 {
     int lo = 0, hi = nchains;  // chain of this tile
     while (hi - lo > 1) {
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(64) void chain_invert(const double *__restrict__ Mp
     const bool live = c < w;
     const int cc = min(c, w - 1);
     __shared__ double stage[64][8];
-    for (int I0 = c0; I0 < w; I0 += 64) {
+    const int wend = diag_only ? min(w, c0 + 64) : w;
+    for (int I0 = c0; I0 < wend; I0 += 64) {
         const int rows = min(64, w - I0);  // wave-uniform
         double acc[64];
 #pragma unroll
@@ -177,6 +179,84 @@ __global__ __launch_bounds__(64) void chain_invert(const double *__restrict__ Mp
         }
         __builtin_amdgcn_s_waitcnt(0);  // the rows just written are read back by the next row blocks
     }
+}
+
+// ---- blocked inverse of a chain's triangle on the matrix cores ---------------------------------------------------------
+// M = [A 0; C B]  =>  M^-1 = [A^-1 0; -B^-1 C A^-1, B^-1]: the 64 x 64 diagonal blocks are inverted by chain_invert(diag_only),
+// then blocks are paired level by level (1 + 1, 2 + 2, 4 + 4 ... blocks of 64), each level two launches of 64 x 64 output
+// tiles: T = C Z11 (mode 1: left operand from M, right from the inverse so far, into a scratch pool) and Z21 = -Z22 T
+// (mode 2: left from the inverse, right from the scratch pool, into the inverse).  The host lists the tiles of every level
+// once per programme (ChainTile).  One wavefront per tile: 4 x 4 accumulators of v_mfma_f64_16x16x4_f64, K restricted to
+// where the triangular operand is not zero.  (One wavefront per 64 columns walking all row blocks in turn -- chain_invert
+// without diag_only -- took 3.7 ms per triangle at a 1024^2 Laplacian, the 1024-wide root separator's first tile alone.)
+struct ChainTile {
+    int64_t pool_off;
+    int32_t w, r0, c0, k0, k1, pad;
+};
+
+typedef double rf_f64x4 __attribute__((ext_vector_type(4)));
+
+// (no __restrict__ on the pools: mode 2 reads and writes the inverse -- disjoint blocks of it)
+__global__ __launch_bounds__(64) void chain_gemm(const double *Lpool, const double *Rpool, double *Opool, const ChainTile *__restrict__ tiles, int negate)
+{
+    const ChainTile T = tiles[blockIdx.x];
+    const int lane = threadIdx.x, m = lane & 15, g = lane >> 4, w = T.w;
+    const double *L = Lpool + T.pool_off, *R = Rpool + T.pool_off;
+    double *O = Opool + T.pool_off;
+    rf_f64x4 acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = rf_f64x4{0.0, 0.0, 0.0, 0.0};
+    // rows and columns beyond the chain (w is any number >= 25) read a valid address and contribute zeros
+    int64_t lrow[4];
+    bool lin[4];
+    int rcol[4];
+    bool rin[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = T.r0 + 16 * t + m, c = T.c0 + 16 * t + m;
+        lin[t] = r < w;
+        lrow[t] = (int64_t)min(r, w - 1) * w;
+        rin[t] = c < w;
+        rcol[t] = min(c, w - 1);
+    }
+    // four K-steps per pass: their 32 loads are in flight together (one K-step per round trip made a 512-long product 200 us)
+    for (int k = T.k0; k < T.k1; k += 16) {
+        double a[4][4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k + 4 * u + g;
+            const bool kin = kk < T.k1;
+            const int kc = min(kk, w - 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double av = L[lrow[t] + kc], bv = R[(int64_t)kc * w + rcol[t]];
+                a[u][t] = kin && lin[t] ? av : 0.0;
+                b[u][t] = kin && rin[t] ? bv : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][rt], b[u][ct], acc[rt][ct], 0, 0, 0);
+    }
+    // element s of a lane is row 4 s + g, column m of its 16 x 16 tile
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = T.r0 + 16 * rt + 4 * s + g;
+            if (r < w) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int c = T.c0 + 16 * ct + m;
+                    if (c < w) O[(int64_t)r * w + c] = negate ? -acc[rt][ct][s] : acc[rt][ct][s];
+                }
+            }
+        }
 }
 
 }  // namespace dev

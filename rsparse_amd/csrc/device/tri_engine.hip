@@ -354,6 +354,39 @@ void TriSolver::build_device_recipe(const CscView &T)
     if (!chains.empty()) RSP_HIP(hipMemcpy(D.chains.get(), chains.data(), chains.size() * sizeof(dev::ChainDesc), hipMemcpyHostToDevice));
     D.pool.resize((size_t)std::max<i64>(R.pool_size, 1));
     D.mpool.resize((size_t)std::max<i64>(R.pool_size, 1));
+    D.tpool.resize((size_t)std::max<i64>(R.pool_size, 1));
+    {
+        // the blocked inverse's tiles: blocks of 64 paired level by level (refill_kernels.hip: chain_gemm)
+        std::vector<dev::ChainTile> t1, t2;
+        D.tile_levels.clear();
+        i64 max_blocks = 0;
+        for (const dev::ChainDesc &c : chains) max_blocks = std::max<i64>(max_blocks, (c.w + 63) / 64);
+        for (i64 half = 1; half < max_blocks; half *= 2) {
+            const i64 first = (i64)t1.size();
+            for (const dev::ChainDesc &c : chains) {
+                const i64 nb = (c.w + 63) / 64;
+                for (i64 g0 = 0; g0 < nb; g0 += 2 * half) {
+                    const i64 a0 = g0, a1 = std::min(g0 + half, nb), b0 = a1, b1 = std::min(g0 + 2 * half, nb);
+                    for (i64 i = b0; i < b1; ++i)
+                        for (i64 j = a0; j < a1; ++j) {
+                            // T[i][j] = sum_k C[i][k] Z11[k][j], k from column block j on (Z11 is lower triangular)
+                            t1.push_back(dev::ChainTile{c.pool_off, c.w, (int32_t)(64 * i), (int32_t)(64 * j), (int32_t)(64 * j),
+                                                        (int32_t)std::min<i64>(64 * a1, c.w), 0});
+                            // Z21[i][j] = -sum_k Z22[i][k] T[k][j], k up to row block i (Z22 is lower triangular)
+                            t2.push_back(dev::ChainTile{c.pool_off, c.w, (int32_t)(64 * i), (int32_t)(64 * j), (int32_t)(64 * b0),
+                                                        (int32_t)std::min<i64>(64 * (i + 1), c.w), 0});
+                        }
+                }
+            }
+            D.tile_levels.emplace_back(first, (i64)t1.size() - first);
+        }
+        D.tiles1.resize(std::max<size_t>(1, t1.size() * sizeof(dev::ChainTile)));
+        D.tiles2.resize(std::max<size_t>(1, t2.size() * sizeof(dev::ChainTile)));
+        if (!t1.empty()) {
+            RSP_HIP(hipMemcpy(D.tiles1.get(), t1.data(), t1.size() * sizeof(dev::ChainTile), hipMemcpyHostToDevice));
+            RSP_HIP(hipMemcpy(D.tiles2.get(), t2.data(), t2.size() * sizeof(dev::ChainTile), hipMemcpyHostToDevice));
+        }
+    }
     D.ncoef = (i64)R.coef_src.size();
     D.ngroups = ngroups;
     D.ntri = (i64)R.tri16.size();
@@ -379,8 +412,19 @@ bool TriSolver::refresh_device(const CscView &T, const double *dTx, hipStream_t 
         RSP_HIP(hipMemsetAsync(D.pool.get(), 0, (size_t)D.pool_size * sizeof(double), stream));
         hipLaunchKernelGGL(dev::chain_fill, blocks(D.nchain_entries), dim3(256), 0, stream, D.mpool.get(), D.chain_pos.get(), D.chain_code.get(),
                            D.nchain_entries, S);
+        // the inverses: 64 x 64 diagonal blocks by substitution, the rest by matrix-core products level by level
+        // (RSP_CHAIN_INVERT_BLOCKED=0: one wavefront per 64 columns walks all row blocks, the round-2 kernel)
+        const bool blocked_inverse = !(getenv("RSP_CHAIN_INVERT_BLOCKED") && getenv("RSP_CHAIN_INVERT_BLOCKED")[0] == '0');
         hipLaunchKernelGGL(dev::chain_invert, dim3((unsigned)D.ntiles), dim3(64), 0, stream, D.mpool.get(), D.pool.get(),
-                           reinterpret_cast<const dev::ChainDesc *>(D.chains.get()), D.nchains);
+                           reinterpret_cast<const dev::ChainDesc *>(D.chains.get()), D.nchains, blocked_inverse ? 1 : 0);
+        if (blocked_inverse)
+            for (const auto &lv : D.tile_levels) {
+                if (!lv.second) continue;
+                const dev::ChainTile *t1 = reinterpret_cast<const dev::ChainTile *>(D.tiles1.get()) + lv.first;
+                const dev::ChainTile *t2 = reinterpret_cast<const dev::ChainTile *>(D.tiles2.get()) + lv.first;
+                hipLaunchKernelGGL(dev::chain_gemm, dim3((unsigned)lv.second), dim3(64), 0, stream, D.mpool.get(), D.pool.get(), D.tpool.get(), t1, 0);
+                hipLaunchKernelGGL(dev::chain_gemm, dim3((unsigned)lv.second), dim3(64), 0, stream, D.pool.get(), D.tpool.get(), D.pool.get(), t2, 1);
+            }
     }
     if (D.ntri)
         hipLaunchKernelGGL(dev::refill_tri16, dim3((unsigned)((D.ntri + 15) / 16)), dim3(256), 0, stream, blocked_.coef.get(), D.tri16.get(), D.ntri, S);
