@@ -234,7 +234,7 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order);
  * library analyses that pattern as a multi-use handle; later calls with the same (device, n, order, pattern of A) --
  * compared entry by entry -- refactorise on it and solve (C2: 1.7 s -> tens of milliseconds).  RSP_ANALYSIS_CACHE = number
  * of patterns kept (default 2, 0 switches the cache off), RSP_ANALYSIS_CACHE_MB = device memory they may hold (default
- * 16384); least recently used entries leave first.  rsp_cache_stats: out[0..6] = hits, misses, entries, estimated device
+ * 16384), RSP_ANALYSIS_CACHE_MIN_N = smallest system that is cached (default 4000 unknowns); least recently used entries leave first.  rsp_cache_stats: out[0..6] = hits, misses, entries, estimated device
  * bytes, background analyses in flight, inserted, evicted.  rsp_cache_clear waits for the background analyses and frees
  * every cached handle (call it before the process ends if device memory must be returned in an orderly way).
  * rsp_lusol_f64 shares the cache (and its counters): a call whose factorisation ran on the device (diagonal pivots) leaves

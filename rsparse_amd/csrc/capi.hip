@@ -910,6 +910,9 @@ int64_t cache_env(const char *name, int64_t fallback)
 }
 int64_t chol_cache_capacity() { return std::max<int64_t>(0, cache_env("RSP_ANALYSIS_CACHE", 2)); }
 int64_t chol_cache_budget() { return std::max<int64_t>(0, cache_env("RSP_ANALYSIS_CACHE_MB", 16384)) << 20; }
+// systems smaller than this are not cached: a whole call costs a few milliseconds there, and a stream of small systems with
+// different patterns (BASELINE.json's batch variant B) would only feed the background thread
+int64_t chol_cache_min_n() { return std::max<int64_t>(1, cache_env("RSP_ANALYSIS_CACHE_MIN_N", 4000)); }
 
 bool same_pattern(const CholCacheEntry &e, const rsp_csc_f64 *A)
 {
@@ -1023,7 +1026,7 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
     uint64_t hash = 0;
     int device = 0;
     bool spawn = false;
-    if (capacity > 0 && A->n > 0) {
+    if (capacity > 0 && A->n >= chol_cache_min_n()) {
         int st = guarded([&] {
             if (int rd = require_device()) return rd;
             RSP_HIP(hipGetDevice(&device));
@@ -1588,7 +1591,7 @@ int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol)
     uint64_t hash = 0;
     int device = 0;
     bool may_insert = false;
-    if (capacity > 0 && A->n > 0) {
+    if (capacity > 0 && A->n >= chol_cache_min_n()) {
         int st = guarded([&] {
             if (int rd = require_device()) return rd;
             RSP_HIP(hipGetDevice(&device));

@@ -271,6 +271,7 @@ def test_lusol_analysis_cache(monkeypatch):
 
 def test_lusol_cache_entry_leaves_when_its_pivots_move(monkeypatch):
     monkeypatch.setenv("RSP_LU_GPU", "1")
+    monkeypatch.setenv("RSP_ANALYSIS_CACHE_MIN_N", "1")  # (400 unknowns: below the size the cache bothers with by default)
     rs.cache_clear()
     A = synth.banded_unsymmetric(400, 5, 8, 9)
     W = _weak_diagonal(400)
@@ -283,7 +284,13 @@ def test_lusol_cache_entry_leaves_when_its_pivots_move(monkeypatch):
     x = b.copy(); rs.lusol(W, x, 1, 1.0)  # a hit whose device check fires: host routine, same answer, entry gone
     assert np.max(np.abs(x - want)) / np.max(np.abs(want)) <= 1e-8
     assert rs.cache_stats()["entries"] == 0
+    # below the default minimum size nothing is kept either
+    monkeypatch.delenv("RSP_ANALYSIS_CACHE_MIN_N")
+    x = b.copy(); rs.lusol(A, x, 1, 1.0)
+    _wait_for_cache()
+    assert rs.cache_stats()["entries"] == 0
     # and with the cache switched off nothing is kept
+    monkeypatch.setenv("RSP_ANALYSIS_CACHE_MIN_N", "1")
     monkeypatch.setenv("RSP_ANALYSIS_CACHE", "0")
     x = b.copy(); rs.lusol(A, x, 1, 1.0)
     _wait_for_cache()
