@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 3: the blocked engine's level kernels and the supernodal engine's sn_gemm on the same factor, no stream overlap
+# round 3: the blocked engine's level kernels and the supernodal engine's sn_gemm on the same factor, no stream overlap.
+# HISTORICAL: ran at commit 84ad225's parent, before the supernodal engine (RSP_SUPERNODAL) was removed; its output is
+# profiles/r03_blocked_vs_sn_kstats.txt.  Kept as the record of how that file was made; it no longer runs as is.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 set -o pipefail
 timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-rhs 0 --skip-extras > gpurun_out/r3_base.json 2> gpurun_out/r3_base.err || { echo BASE FAILED; tail -5 gpurun_out/r3_base.err; exit 1; }
