@@ -137,6 +137,49 @@ def spawn_ranks(args):
     sys.exit(0 if all(c == 0 for c in codes) else 1)
 
 
+def lu_c4_extras(rs, synth, np):
+    """SURVEY 8f item 2 beside the headline figure: numeric LU of BASELINE.json's C4 matrix (banded-random, 200 000 unknowns,
+    lusol(order=1, tol=1.0)) by the host routine (the reference's algorithm, one thread) and by the GPU path (patterns on the
+    host, values by lu_columns, pivot rule checked on the device), the factors compared BIT FOR BIT; a refactorisation on the
+    same pattern; the one-shot lusol and the same call again (analysis cache)."""
+    out = {}
+    A = rs.Sprs.from_tuple(synth.banded_unsymmetric(200000))
+    S = rs.sqr(A, 1)
+    old = os.environ.get("RSP_LU_GPU")
+    try:
+        os.environ["RSP_LU_GPU"] = "0"
+        t0 = time.time(); H = rs.lu(A, S, 1.0); out["host_s"] = time.time() - t0
+        os.environ.pop("RSP_LU_GPU")
+        t0 = time.time(); G = rs.lu(A, S, 1.0); out["gpu_s"] = time.time() - t0
+    finally:
+        if old is not None:
+            os.environ["RSP_LU_GPU"] = old
+    out["on_device"] = bool(G.on_device)
+    out["bit_identical_to_host_routine"] = bool(
+        np.array_equal(H.pinv, G.pinv) and np.array_equal(H.l.p, G.l.p) and np.array_equal(H.l.i, G.l.i) and np.array_equal(H.u.p, G.u.p)
+        and np.array_equal(H.u.i, G.u.i) and np.array_equal(H.l.x.view(np.int64), G.l.x.view(np.int64))
+        and np.array_equal(H.u.x.view(np.int64), G.u.x.view(np.int64)))
+    out["nnz_L"], out["nnz_U"] = int(G.l.p[-1]), int(G.u.p[-1])
+    del H
+    A2 = rs.Sprs(A.m, A.n, A.p, A.i, A.x * 1.01)
+    t0 = time.time(); G.refactor(A2, 1.0); out["refactor_s"] = time.time() - t0
+    out["refactor_on_device"] = bool(G.on_device)
+    del G
+    b = synth.splitmix64(5, A.n)
+    rs.cache_clear()
+    x = b.copy()
+    t0 = time.time(); rs.lusol(A, x, 1, 1.0); out["lusol_one_shot_s"] = time.time() - t0
+    t0 = time.time()
+    while rs.cache_stats()["pending"] and time.time() - t0 < 120:
+        time.sleep(0.01)
+    x = b.copy()
+    t0 = time.time(); rs.lusol(A2, x, 1, 1.0); out["lusol_cached_s"] = time.time() - t0
+    r = rs.gaxpy(A2, x, -b)
+    out["lusol_cached_residual_rel"] = float(np.linalg.norm(r) / np.linalg.norm(b))
+    rs.cache_clear()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +322,8 @@ def main():
                 extras["cholsol_cached_x_error"] = float(np.max(np.abs(xe - xstar)) / np.max(np.abs(xstar)))
                 extras["cholsol_cache"] = rs.cache_stats()
                 rs.cache_clear()
+        if not args.skip_extras and args.config == "c2":
+            extras["lu_c4"] = lu_c4_extras(rs, synth, np)
         extras["chol_factor_first_call_ms"] = F.info()["factor_ms"]  # includes first-launch costs of every kernel
         if not args.skip_extras:
             # a time step of an implicit solver: new values on the same pattern, then a solve.  The resident solve programmes
