@@ -256,7 +256,7 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
  * rsparse::lu (src/lib.rs:519-622): left-looking LU with threshold partial pivoting.  The values are computed on the GPU
  * when every column keeps its DIAGONAL as pivot under the reference's rule (|diag| >= tol * max|x|, lib.rs:585-589) -- the
  * patterns then follow from integer work on the host, the columns run on the device in one persistent launch (one
- * wavefront per column, in the reference's order of operations), every column checks the rule, and the factors are
+ * wavefront per column, columns taken by dependency level, each in the reference's order of operations), every column checks the rule, and the factors are
  * bit-identical to the reference's, values included.  Any column that breaks the rule, a matrix with a structurally missing
  * diagonal or duplicate entries in a column, tol > 1, or too little work to pay for the device set-up (< 1e8
  * multiply-subtracts) send the whole factorisation to the host routine instead (the reference's algorithm, sequential; the

@@ -1330,7 +1330,15 @@ int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
             if (N->device->factor(A->x, tol) == kOk) {
                 N->device->download(N->f);
                 if (N->lower) {
-                    if (N->lower->refresh_host(N->f.L.view()) && N->upper->refresh_host(N->f.U.view())) {
+                    // resident solve programmes take the new coefficients in place: on the device, straight from the values
+                    // lu_columns left there (refill kernels), else on the host through the same recipe, else they are dropped
+                    // and analysed again at the next solve
+                    const bool on_device = !(getenv("RSP_REFILL_DEVICE") && getenv("RSP_REFILL_DEVICE")[0] == '0') &&
+                                           N->lower->refresh_device(N->f.L.view(), N->device->dLx(), nullptr) &&
+                                           N->upper->refresh_device(N->f.U.view(), N->device->dUx(), nullptr);
+                    if (on_device) {
+                        RSP_HIP(hipDeviceSynchronize());
+                    } else if (N->lower->refresh_host(N->f.L.view()) && N->upper->refresh_host(N->f.U.view())) {
                         N->lower->refresh_upload();
                         N->upper->refresh_upload();
                     } else {
@@ -1557,6 +1565,13 @@ void lu_cache_prepare(std::unique_ptr<CholCacheEntry> e)
             }
             std::vector<double> zero((size_t)e->n, 0.0);
             ok = rsp_lu_solve_f64(N, e->S.get(), zero.data(), e->n, 1) == RSP_OK;
+            if (ok) {  // the refill recipes go to the device now, not at the first hit
+                std::lock_guard<std::mutex> lock(N->guard.m);
+                if (N->lower && N->upper) {
+                    N->lower->prepare_refresh_device(N->f.L.view());
+                    N->upper->prepare_refresh_device(N->f.U.view());
+                }
+            }
             e->bytes = (int64_t)(N->f.L.i.size() + N->f.U.i.size()) * 40 + N->device->device_bytes();
         }
     } catch (...) {
