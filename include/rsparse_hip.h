@@ -276,7 +276,9 @@ int rsp_lu_on_device(const rsp_lu *N); /* 1: the values came from the GPU numeri
  * lu again (lib.rs:519); the result is what that call would give, bit for bit.  When N came from the GPU numeric LU the
  * kernel alone runs again -- no depth-first search, no new analysis, resident solve programmes get the new coefficients --
  * as long as every column still keeps its diagonal as pivot; otherwise the host routine factors A (the pivot sequence may
- * change; solves are analysed again at their next use).  Not concurrent with solves on the same handle. */
+ * change; solves are analysed again at their next use).  RSP_NO_PIVOT (a singular matrix) leaves the handle WITHOUT a
+ * factorisation: solves and views return RSP_NO_PIVOT until a refactorisation succeeds.  Not concurrent with solves on the
+ * same handle.  The host views (rsp_lu_L / rsp_lu_U) fetch the new values from the device when they are next asked for. */
 int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol);
 /* b <- A^-1 b for nrhs host column-major right-hand sides (ipvec, lsolve, usolve, ipvec: src/lib.rs:678-681) */
 int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64_t nrhs);

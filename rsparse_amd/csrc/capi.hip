@@ -82,6 +82,10 @@ struct rsp_lu {
     bool on_device = false;                   // the values came from the GPU numeric LU (static pivots held), not from host/lu.cpp
     std::unique_ptr<LuDevice> device;         // ... and its device half, for rsp_lu_refactor_f64
     std::vector<int64_t> q_factor;            // the column order the factorisation was made with (empty: natural)
+    bool valid = true;                        // false after a refactorisation that found no pivot: the handle holds NO
+                                              // factorisation until a refactorisation succeeds (solves return RSP_NO_PIVOT)
+    bool values_on_device_only = false;       // a refactorisation left the new values of L and U on the device: the host copy
+                                              // (f.L.x, f.U.x) is brought up to date when somebody asks for it
     uint64_t pattern = 0;                     // pattern_hash of the matrix that was factored, and its entry count:
     int64_t pattern_nnz = -1;                 // rsp_lu_refactor_f64 takes new values on that pattern only
     DeviceBuffer<int64_t> d_pinv, d_q;        // rsp_lu_solve_dev_f64: the two permutations on the device
@@ -1282,18 +1286,27 @@ static void fill_view(const Csc &M, rsp_csc_f64 *out)
     out->x = M.x.data();
 }
 
-int rsp_lu_L(const rsp_lu *N, rsp_csc_f64 *L)
+// the host copy of the factors' values, after a refactorisation that left them on the device (caller holds the guard)
+static void lu_pull_values(rsp_lu *N)
 {
-    if (!N || !L) return RSP_BAD_INPUT;
-    fill_view(N->f.L, L);
-    return RSP_OK;
+    if (!N->values_on_device_only) return;
+    N->device->download(N->f);
+    N->values_on_device_only = false;
 }
-int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U)
+static int lu_host_view(const rsp_lu *N_, bool lower, rsp_csc_f64 *out)
 {
-    if (!N || !U) return RSP_BAD_INPUT;
-    fill_view(N->f.U, U);
-    return RSP_OK;
+    if (!N_ || !out) return RSP_BAD_INPUT;
+    rsp_lu *N = const_cast<rsp_lu *>(N_);  // (the handle is logically unchanged: its host copy catches up with the device)
+    return guarded([&] {
+        std::lock_guard<std::mutex> lock(N->guard.m);
+        if (!N->valid) return (int)RSP_NO_PIVOT;
+        lu_pull_values(N);
+        fill_view(lower ? N->f.L : N->f.U, out);
+        return (int)RSP_OK;
+    });
 }
+int rsp_lu_L(const rsp_lu *N, rsp_csc_f64 *L) { return lu_host_view(N, true, L); }
+int rsp_lu_U(const rsp_lu *N, rsp_csc_f64 *U) { return lu_host_view(N, false, U); }
 const int64_t *rsp_lu_pinv(const rsp_lu *N) { return N ? N->f.pinv.data() : nullptr; }
 int rsp_lu_static_pattern_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_lu **N, int64_t *nlevels)
 {
@@ -1328,7 +1341,7 @@ int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
             if (!N->device->same_pattern(Av)) return (int)RSP_BAD_INPUT;
             RSP_HIP(hipDeviceSynchronize());  // solves still in flight read the coefficients that are about to change
             if (N->device->factor(A->x, tol) == kOk) {
-                N->device->download(N->f);
+                N->values_on_device_only = true;  // (downloaded when the host view, a host refill or a new analysis asks for them)
                 if (N->lower) {
                     // resident solve programmes take the new coefficients in place: on the device, straight from the values
                     // lu_columns left there (refill kernels), else on the host through the same recipe, else they are dropped
@@ -1338,12 +1351,15 @@ int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
                                            N->upper->refresh_device(N->f.U.view(), N->device->dUx(), nullptr);
                     if (on_device) {
                         RSP_HIP(hipDeviceSynchronize());
-                    } else if (N->lower->refresh_host(N->f.L.view()) && N->upper->refresh_host(N->f.U.view())) {
-                        N->lower->refresh_upload();
-                        N->upper->refresh_upload();
                     } else {
-                        N->lower.reset();
-                        N->upper.reset();
+                        lu_pull_values(N);
+                        if (N->lower->refresh_host(N->f.L.view()) && N->upper->refresh_host(N->f.U.view())) {
+                            N->lower->refresh_upload();
+                            N->upper->refresh_upload();
+                        } else {
+                            N->lower.reset();
+                            N->upper.reset();
+                        }
                     }
                 }
                 return (int)RSP_OK;
@@ -1353,12 +1369,15 @@ int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
         // the host routine, with the column order of the first factorisation
         if (N->lower) RSP_HIP(hipDeviceSynchronize());
         LuFactors f;
-        if (int st = sparse_lu(Av, N->q_factor.empty() ? nullptr : N->q_factor.data(), tol, f)) return st;
-        N->f = std::move(f);
+        const int st = sparse_lu(Av, N->q_factor.empty() ? nullptr : N->q_factor.data(), tol, f);
+        N->values_on_device_only = false;
         N->on_device = false;
         N->lower.reset();
         N->upper.reset();
         N->d_pinv = DeviceBuffer<int64_t>();
+        N->valid = st == kOk;  // (no pivot: what the handle held is gone with the programmes, and nothing replaces it)
+        if (st) return st;
+        N->f = std::move(f);
         return (int)RSP_OK;
     });
 }
@@ -1367,6 +1386,7 @@ int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
 static int lu_solvers(rsp_lu *N)
 {
     if (N->lower) return RSP_OK;
+    lu_pull_values(N);  // (the analysis reads the values from the host copy)
     std::unique_ptr<TriSolver> lo(new TriSolver), up(new TriSolver);
     if (N->device && !N->single_use) {  // a refactorisation may follow: the programmes keep the recipe for new coefficients
         lo->keep_for_refill();
@@ -1384,6 +1404,7 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
     return guarded([&] {
         if (int st = require_device()) return st;
         std::lock_guard<std::mutex> lock(N->guard.m);
+        if (!N->valid) return (int)RSP_NO_PIVOT;
         const int64_t n = N->f.L.n;
         if (int st = lu_solvers(N)) return st;
         // x = P b (host gather, 16 MB per million unknowns), L and U solves on the GPU, b = Q x
@@ -1410,6 +1431,7 @@ int rsp_lu_solve_dev_f64(rsp_lu *N, const rsp_symb *S, double *dB, int layout, i
     if (nrhs == 0 || N->f.L.n == 0) return RSP_OK;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(N->guard.m);
+        if (!N->valid) return (int)RSP_NO_PIVOT;
         hipStream_t stream = (hipStream_t)stream_;
         const int64_t n = N->f.L.n;
         if (int st = lu_solvers(N)) return st;

@@ -296,3 +296,54 @@ def test_lusol_cache_entry_leaves_when_its_pivots_move(monkeypatch):
     _wait_for_cache()
     assert rs.cache_stats()["entries"] == 0
     rs.cache_clear()
+
+
+def test_gpu_lu_refactorisation_without_a_pivot_leaves_no_factorisation(monkeypatch):
+    """New values that make the matrix singular: the reference's lu returns NoPivot (lib.rs:583); so does the refactorisation,
+    and the handle then holds nothing until a refactorisation succeeds (as a failed Cholesky refactorisation does)."""
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = synth.banded_unsymmetric(600, band=20)
+    m, n, p, i, x = A
+    Z = (m, n, p, i, x.copy())
+    Z[4][p[300]:p[301]] = 0.0  # a column of zeros, same pattern
+    assert orc.lu(Z, 1, 1.0)[0] != orc.OK
+    S = rs.sqr(A, 1)
+    N = rs.lu(A, S, 1.0)
+    assert N.on_device
+    b = 2.0 * synth.splitmix64(9, n) - 1.0
+    y = b.copy()
+    N.solve(y)
+    with pytest.raises(rs.NoPivot):
+        N.refactor(Z, 1.0)
+    with pytest.raises(rs.NoPivot):
+        N.solve(b.copy())
+    with pytest.raises(rs.NoPivot):
+        _ = N.l
+    N.refactor(A, 1.0)  # (on the host from here on)
+    st, want = orc.lu(A, 1, 1.0)
+    _same_bits(N, want)
+    z = b.copy()
+    N.solve(z)
+    assert np.max(np.abs(z - y)) / np.max(np.abs(y)) <= 1e-10
+
+
+def test_gpu_lu_host_views_follow_a_refactorisation(monkeypatch):
+    """The values of a refactorisation stay on the device until somebody asks: the views must then be the new factors."""
+    monkeypatch.setenv("RSP_LU_GPU", "1")
+    A = synth.banded_unsymmetric(3000, 5, 10, 1)
+    S = rs.sqr(A, 1)
+    N = rs.lu(A, S, 1.0)
+    b = 2.0 * synth.splitmix64(4, 3000) - 1.0
+    x = b.copy()
+    N.solve(x)  # resident programmes: the refactorisation refills them on the device and downloads nothing
+    A2 = _revalued(A, 7)
+    N.refactor(A2, 1.0)
+    x = b.copy()
+    N.solve(x)
+    st, ref = orc.lusol(A2, b, 1, 1.0)
+    assert np.max(np.abs(x - ref)) / np.max(np.abs(ref)) <= 1e-8
+    st, want = orc.lu(A2, 1, 1.0)
+    _same_bits(N, want)  # (the views fetch the values now)
+    N.refactor(A, 1.0)
+    st, want = orc.lu(A, 1, 1.0)
+    _same_bits(N, want)
