@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -773,17 +774,19 @@ static int chol_factor_impl(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **
 
 int rsp_chol_factor_f64(const rsp_csc_f64 *A, const rsp_symb *S, rsp_chol **F) { return chol_factor_impl(A, S, F, false); }
 
-int rsp_chol_refactor_f64(rsp_chol *F, const rsp_csc_f64 *A)
+// pattern_verified: the caller has compared A's pattern with the analysed one entry by entry (the analysis cache)
+static int chol_refactor_impl(rsp_chol *F, const rsp_csc_f64 *A, bool pattern_verified)
 {
     if (!F || !sane(A) || A->m != A->n || A->n != F->f.n() || A->p[A->n] != F->f.annz()) return RSP_BAD_INPUT;
     return guarded([&] {
         std::lock_guard<std::mutex> lock(F->guard.m);
         // the values are scattered through the analysed pattern's maps: another pattern of the same size would give a wrong
         // factor without any error
-        if (pattern_hash(view_of(A)) != F->f.pattern()) return (int)RSP_BAD_INPUT;
+        if (!pattern_verified && pattern_hash(view_of(A)) != F->f.pattern()) return (int)RSP_BAD_INPUT;
         return F->f.factorize(view_of(A));  // same analysis, same launches; the solve programmes receive the values on the next solve
     });
 }
+int rsp_chol_refactor_f64(rsp_chol *F, const rsp_csc_f64 *A) { return chol_refactor_impl(F, A, false); }
 
 int rsp_chol_f64(const rsp_csc_f64 *A, const rsp_symb *S, int64_t *Lp, uint64_t *Li, double *Lx)
 {
@@ -918,10 +921,19 @@ int64_t chol_cache_budget() { return std::max<int64_t>(0, cache_env("RSP_ANALYSI
 // different patterns (BASELINE.json's batch variant B) would only feed the background thread
 int64_t chol_cache_min_n() { return std::max<int64_t>(1, cache_env("RSP_ANALYSIS_CACHE_MIN_N", 4000)); }
 
+// entry by entry, on the host threads (50 MB at a million unknowns: 5 ms on one thread, a sixth of a cached call)
 bool same_pattern(const CholCacheEntry &e, const rsp_csc_f64 *A)
 {
-    return e.n == A->n && e.nnz == A->p[A->n] && std::memcmp(e.p.data(), A->p, (size_t)(A->n + 1) * sizeof(int64_t)) == 0 &&
-           std::memcmp(e.i.data(), A->i, (size_t)e.nnz * sizeof(int64_t)) == 0;
+    if (e.n != A->n || e.nnz != A->p[A->n]) return false;
+    std::atomic<bool> same{true};
+    auto compare = [&](const int64_t *a, const int64_t *b, int64_t count) {
+        parallel_ranges(count, 1 << 18, [&](int64_t lo, int64_t hi) {
+            if (std::memcmp(a + lo, b + lo, (size_t)(hi - lo) * sizeof(int64_t)) != 0) same.store(false);
+        });
+    };
+    compare(e.p.data(), A->p, A->n + 1);
+    if (same.load()) compare(e.i.data(), reinterpret_cast<const int64_t *>(A->i), e.nnz);
+    return same.load();
 }
 
 // entries beyond the budgets leave, least recently used first (the caller holds the cache's mutex); returns what must be freed
@@ -1057,7 +1069,7 @@ int rsp_cholsol_f64(const rsp_csc_f64 *A, double *b, int8_t order)
             hit.reset();
         }
         if (hit) {
-            st = rsp_chol_refactor_f64(hit->F.get(), A);  // numeric Cholesky on the cached analysis (GPU)
+            st = chol_refactor_impl(hit->F.get(), A, true);  // numeric Cholesky on the cached analysis (GPU)
             const double t1 = clock();
             if (st == RSP_OK) st = rsp_chol_solve_f64(hit->F.get(), b, A->n, 1);  // P, lsolve, ltsolve, P' through the resident programmes
             if (getenv("RSP_TIMING")) fprintf(stderr, "cholsol (cached analysis): refactor %.3fs, solve %.3fs\n", t1 - t0, clock() - t1);
@@ -1338,7 +1350,6 @@ int rsp_lu_refactor_f64(rsp_lu *N, const rsp_csc_f64 *A, double tol)
         const CscView Av = view_of(A);
         if (N->pattern_nnz != Av.nnz() || N->pattern != pattern_hash(Av)) return (int)RSP_BAD_INPUT;
         if (N->device) {
-            if (!N->device->same_pattern(Av)) return (int)RSP_BAD_INPUT;
             RSP_HIP(hipDeviceSynchronize());  // solves still in flight read the coefficients that are about to change
             if (N->device->factor(A->x, tol) == kOk) {
                 N->values_on_device_only = true;  // (downloaded when the host view, a host refill or a new analysis asks for them)
