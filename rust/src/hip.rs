@@ -9,6 +9,7 @@ use crate::Error;
 struct Csc { nzmax: i64, m: i64, n: i64, p: *const isize, i: *const usize, x: *const f64 }   // rsp_csc_f64
 #[repr(C)] struct RspSymb { _p: [u8; 0] }
 #[repr(C)] struct RspChol { _p: [u8; 0] }
+#[repr(C)] struct RspLu { _p: [u8; 0] }
 
 extern "C" {
     fn rsp_lsolve_f64 (l: *const Csc, x: *mut f64) -> i32;     // replaces lsolve   src/lib.rs:464
@@ -24,6 +25,15 @@ extern "C" {
                            s: *mut *mut RspSymb) -> i32;
     fn rsp_chol_f64(a: *const Csc, s: *const RspSymb, lp: *mut isize, li: *mut usize, lx: *mut f64) -> i32; // chol :278
     fn rsp_symb_free(s: *mut RspSymb);
+    // lu (src/lib.rs:519) on a Symb from sqr: the reference's factors bit for bit (values from the GPU when every column keeps
+    // its diagonal as pivot, else from the host routine); L, U, pinv are borrowed views of Nmrc.l / .u / .pinv
+    fn rsp_sqr_lu(a: *const Csc, order: i8, s: *mut *mut RspSymb) -> i32;                      // sqr(a, order, false) :1114
+    fn rsp_lu_f64(a: *const Csc, s: *const RspSymb, tol: f64, n: *mut *mut RspLu) -> i32;      // lu :519
+    fn rsp_lu_L(n: *const RspLu, l: *mut Csc) -> i32;
+    fn rsp_lu_U(n: *const RspLu, u: *mut Csc) -> i32;
+    fn rsp_lu_pinv(n: *const RspLu) -> *const isize;
+    fn rsp_lu_refactor_f64(n: *mut RspLu, a: *const Csc, tol: f64) -> i32;                     // new values, same pattern (no counterpart)
+    fn rsp_lu_free(n: *mut RspLu);
 }
 
 fn view(a: &Sprs<f64>) -> Csc {
