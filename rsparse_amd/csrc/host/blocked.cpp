@@ -1330,7 +1330,8 @@ class Builder {
     // emit_big_chain: private scratch of the threads that rank the groups of a chain
     i64 emit_threads_ = 0;
     i64 item_rows_ = kItemRows, sort_rows_ = 1, item_min_sources_ = kItemMinSources;
-    double item_min_fill_ = 0.5;        // an item's tiles must use at least this share of its union list, on average
+    double item_min_fill_ = 0.2;        // an item's tiles must use at least this share of its union list, on average (0.5 / 0.3 /
+                                        // 0.2 / 0.1 at C3: 24.5 / 23.4 / 23.3 / 23.2 ms; C2 indifferent: blocks of zeros cost nothing)
     std::vector<char> task_tile_;       // per block task: 1 = a row tile of a wide item
     std::vector<int32_t> item_level_;   // per item, in emission order
     RankedGroup chain_groups_[4];
