@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include <chrono>
+#include <cmath>
 #include <memory>
 
 namespace rsp {
@@ -355,6 +356,20 @@ int lu_numeric_device(const CscView &A, const i64 *q, double tol, LuFactors &out
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return kLuDeclined;
     if (A.nnz() >= INT32_MAX) return kLuDeclined;
+    if (mode != 1) {
+        // A cheap look before the expensive search (which costs as much as half a host factorisation and is wasted when the
+        // device check fails): the pivot rule on the columns of A itself.  It is exact for columns that no earlier column
+        // updates and a heuristic for the rest; a matrix that fails it here would almost surely fail it on the device.
+        for (i64 c = 0; c < n; ++c) {
+            double diag = 0.0, largest = 0.0;
+            for (i64 e = A.p[c]; e < A.p[c + 1]; ++e) {
+                const double a = std::fabs(A.x[e]);
+                if (A.i[e] == c) diag = a;
+                largest = a > largest ? a : largest;
+            }
+            if (!(largest > 0.0) || !(diag >= largest * tol)) return kLuDeclined;
+        }
+    }
     std::vector<int32_t> level;
     LuFactors f;
     const bool trace = getenv("RSP_LU_TRACE") != nullptr;

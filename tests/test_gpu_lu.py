@@ -347,3 +347,27 @@ def test_gpu_lu_host_views_follow_a_refactorisation(monkeypatch):
     N.refactor(A, 1.0)
     st, want = orc.lu(A, 1, 1.0)
     _same_bits(N, want)
+
+
+def test_gpu_lu_default_mode_does_not_try_matrices_whose_columns_fail_the_rule_at_once(monkeypatch):
+    """Default mode (no switch): enough work for the GPU (banded 50 000: 5.6e8 multiply-subtracts), diagonal pivots -> GPU; the
+    same pattern with one diagonal far below its column's maximum fails the pivot rule on A itself: the library goes to the
+    host routine without spending the search on it.  Either way the factors are the host routine's, bit for bit."""
+    monkeypatch.delenv("RSP_LU_GPU", raising=False)
+    m, n, p, i, x = synth.banded_unsymmetric(50000)
+    A = rs.Sprs(m, n, p, i, x)
+    S = rs.sqr(A, 1)
+    assert rs.lu(A, S, 1.0).on_device
+    xw = x.copy()
+    col = n // 3
+    for e in range(p[col], p[col + 1]):
+        if i[e] == col:
+            xw[e] = 1e-9
+    W = rs.Sprs(m, n, p, i, xw)
+    G = rs.lu(W, S, 1.0)
+    assert not G.on_device
+    monkeypatch.setenv("RSP_LU_GPU", "0")
+    H = rs.lu(W, S, 1.0)
+    assert np.array_equal(G.pinv, H.pinv)
+    for g, h in ((G.l, H.l), (G.u, H.u)):
+        assert np.array_equal(g.p, h.p) and np.array_equal(g.i, h.i) and np.array_equal(g.x.view(np.int64), h.x.view(np.int64))
