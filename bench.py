@@ -322,7 +322,7 @@ def main():
                 extras["cholsol_cached_x_error"] = float(np.max(np.abs(xe - xstar)) / np.max(np.abs(xstar)))
                 extras["cholsol_cache"] = rs.cache_stats()
                 rs.cache_clear()
-        if not args.skip_extras and args.config == "c2":
+        if not args.skip_extras and args.config == "c2" and world == 1:
             extras["lu_c4"] = lu_c4_extras(rs, synth, np)
         extras["chol_factor_first_call_ms"] = F.info()["factor_ms"]  # includes first-launch costs of every kernel
         if not args.skip_extras:
