@@ -384,7 +384,12 @@ int lu_numeric_device(const CscView &A, const i64 *q, double tol, LuFactors &out
         for (i64 t = f.U.p[(size_t)k]; t + 1 < f.U.p[(size_t)k + 1]; ++t) updates += (double)(f.L.p[(size_t)f.U.i[(size_t)t] + 1] - f.L.p[(size_t)f.U.i[(size_t)t]] - 1);
     if (mode != 1 && updates < kLuMinUpdates) return kLuDeclined;
     std::unique_ptr<LuDevice> D(new LuDevice);
-    D->setup(A, q, f, level);
+    try {
+        D->setup(A, q, f, level);
+    } catch (const DeviceError &) {  // no room for the work vectors and patterns on the device: the host routine needs none
+        (void)hipGetLastError();
+        return kLuDeclined;
+    }
     const auto t2 = now();
     const int st = D->factor(A.x, tol);
     const auto t3 = now();
