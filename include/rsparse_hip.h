@@ -259,7 +259,7 @@ int rsp_cholsol_batch_f64(const rsp_csc_f64 *A, const double *Ax_all, double *B,
  * wavefront per column, columns taken by dependency level, each in the reference's order of operations), every column checks the rule, and the factors are
  * bit-identical to the reference's, values included.  Any column that breaks the rule, a matrix with a structurally missing
  * diagonal or duplicate entries in a column, tol > 1, a column of A itself that already fails the rule, or too little work
- * to pay for the device set-up (< 1e8 multiply-subtracts) send the whole factorisation to the host routine instead (the reference's algorithm, sequential; the
+ * to pay for the device set-up (< 2e7 multiply-subtracts) send the whole factorisation to the host routine instead (the reference's algorithm, sequential; the
  * same bits).  RSP_LU_GPU=0 forces the host, =1 the GPU whenever the static pivots apply.  rsparse::lusol (src/lib.rs:672-683) then solves with L and U on the GPU. */
 typedef struct rsp_lu rsp_lu;
 int rsp_lu_f64(const rsp_csc_f64 *A, const rsp_symb *S, double tol, rsp_lu **N);
