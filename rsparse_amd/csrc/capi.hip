@@ -1426,6 +1426,8 @@ int rsp_lu_solve_f64(rsp_lu *N, const rsp_symb *S, double *B, int64_t ldb, int64
         N->lower->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
         N->upper->solve_device(d.get(), RSP_COL_MAJOR, n, nrhs, nullptr);
         RSP_HIP(hipDeviceSynchronize());
+        N->lower->check_rows_run();  // (single-use handles: the flagged row kernel reports an abandoned wait here)
+        N->upper->check_rows_run();
         d.download(x.data(), x.size());
         const int64_t *q = S->s.has_q ? S->s.q.data() : nullptr;
         for (int64_t r = 0; r < nrhs; ++r)

@@ -881,6 +881,8 @@ void CholFactor::solve_host(double *B, i64 ldb, i64 nrhs)
     const double t0 = clock();
     solve_device(d.get(), 0, n_, nrhs, true, nullptr);
     RSP_HIP(hipDeviceSynchronize());
+    if (lower_) lower_->check_rows_run();  // (single-use handles: the flagged row kernel reports an abandoned wait here)
+    if (upper_) upper_->check_rows_run();
     if (timing) fprintf(stderr, "chol solve: %lld right-hand side(s) on the device %.3fs\n", (long long)nrhs, clock() - t0);
     copy_block_to_host(B, d.get(), n_, ldb, nrhs);
 }

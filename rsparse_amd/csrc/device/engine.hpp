@@ -183,7 +183,10 @@ class TriSolver {
     // programme (one launch per dependency level, nothing to build) when its launches cost less than building the
     // blocked programme for a single use.  Handles that solve many times never call this.
     void set_single_use();
-    bool single_use_levels() const { return single_use_levels_; }
+    bool single_use_levels() const { return single_use_levels_ || single_use_rows_; }
+    // the flagged row kernel of a single-use handle ran and one of its waits gave up (a defect): call after the stream
+    // has been synchronised; throws DeviceError
+    void check_rows_run();
     // NEW VALUES ON THE ANALYSED PATTERN (a refactorisation).  keep_for_refill() before analyze(): the gather form keeps
     // where each of its values comes from and the blocked programme keeps its recipe (BlockProgram::Refill) and a host
     // copy of its coefficients.  refresh_host(T) then pours the values of T (same pattern) into that copy -- host work
@@ -239,6 +242,18 @@ class TriSolver {
     TriProgram multi_, single_;
     BlockedProgram blocked_;
     bool have_multi_ = false, have_single_ = false, have_blocked_ = false, single_use_levels_ = false;
+    // single use, one vector: rows with flags (solve_rows_flagged) straight from the gather form -- no programme to build
+    bool single_use_rows_ = false, rows_ran_ = false;
+    struct RowsDevice {
+        DeviceBuffer<int64_t> ptr;
+        DeviceBuffer<int32_t> idx, order;
+        DeviceBuffer<double> val, diag;
+        DeviceBuffer<int> done;
+        DeviceBuffer<char> ctl, grabs;  // dev::RowsControl, int2 (first, end) positions of each grab
+        i64 ngrabs = 0;
+        bool uploaded = false;
+    } rows_;
+    void run_rows(double *x, hipStream_t stream);
     std::unique_ptr<BlockProgram> staged_;
     std::unique_ptr<BlockProgram> kept_;  // keep_for_refill(): coef, groups and the recipe of the resident programme
     struct DeviceRecipe {

@@ -105,6 +105,79 @@ __global__ __launch_bounds__(256) void solve_level_single(TriArrays T, int task_
     }
 }
 
+// ---- one vector, one use: rows with flags instead of levels --------------------------------------------------------------
+// A handle that solves ONE vector and is dropped (the reference's one-shot lsolve ... cholsol, lusol) cannot pay for a
+// programme: building the blocked one costs ~20 ns per entry on the host, and the plain level programme is one launch per
+// dependency level (13 500 launches, 0.3 s, at a 1024^2 Laplacian).  This kernel needs the gather form and the rows sorted by
+// dependency level: ONE persistent launch, wavefronts take "grabs" -- up to kRowsPerGrab rows of ONE level, listed by the
+// host -- from a counter; a row whose source x[j] is still in flight waits on that row's flag.  (By level, because in a
+// postordered factor row r mostly depends on row r - 1: rows in index order in flight form one chain.  Several rows per
+// grab, because same-address atomics serialise at ~0.2 us each: a million of them would be the kernel's duration.  The
+// WHOLE wavefront polls ONE flag at a time -- the first unready one -- because 64 lanes polling 64 different flags from
+// thousands of waiting wavefronts saturate the fabric and slow every hand-over down tenfold.)  A row only waits for rows
+// of lower levels, which come earlier in the order and were taken by wavefronts that are running: no deadlock; every wait
+// is bounded besides (a flag that never rises is a defect: the wait gives up and marks the run, every other wait sees the
+// mark, the grid drains, the host reports RSP_DEVICE_ERROR).  x and the flags travel as agent-scope atomics.  Sums are
+// per lane in entry order, then a fixed butterfly: deterministic, independent of timing.
+constexpr int kRowsPerGrab = 8;
+
+struct RowsControl {
+    int next;    // next grab
+    int failed;  // a wait gave up
+    int stuck_row, stuck_source;
+};
+
+__global__ __launch_bounds__(64) void solve_rows_flagged(const int64_t *ptr, const int32_t *idx, const double *val, const double *diag, double *x,
+                                                         int *done, RowsControl *ctl, const int32_t *order, const int2 *grabs, int ngrabs,
+                                                         unsigned spin_limit)
+{
+    const int lane = threadIdx.x;
+    for (;;) {
+        // (every lane adds, 1 or 0, and readfirstlane states the uniformity: see lu_columns for what `if (lane == 0)` did here)
+        int g = atomicAdd(&ctl->next, lane == 0 ? 1 : 0);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngrabs) break;  // every wavefront gets here: the counter only grows
+        const int2 span = grabs[g];
+        for (int t = span.x; t < span.y; ++t) {
+            const int r = __builtin_amdgcn_readfirstlane(order[t]);
+            const double xr = x[r], dr = diag[r];  // (issued ahead of the waits below)
+            double s = 0.0;
+            for (int64_t p0 = ptr[r]; p0 < ptr[r + 1]; p0 += 64) {
+                const bool in = p0 + lane < ptr[r + 1];
+                const int j = in ? idx[p0 + lane] : -1;
+                const double v = in ? val[p0 + lane] : 0.0;
+                bool ready = j < 0 || __hip_atomic_load(done + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                unsigned long long waiting = __ballot(!ready);
+                unsigned spins = 0;
+                while (waiting) {  // (uniform) the whole wavefront polls the first unready source's flag
+                    const int first = __builtin_ctzll(waiting);
+                    const int jw = __builtin_amdgcn_readlane(j, first);
+                    while (__hip_atomic_load(done + jw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if ((++spins & 1023u) == 0) {
+                            if (spins >= spin_limit && lane == 0 && atomicExch(&ctl->failed, 1) == 0) {
+                                ctl->stuck_row = r;
+                                ctl->stuck_source = jw;
+                            }
+                            if (__hip_atomic_load(&ctl->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        }
+                    }
+                    if (__hip_atomic_load(&ctl->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    ready = j < 0 || __hip_atomic_load(done + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    waiting = __ballot(!ready);
+                }
+                if (in) s += v * __hip_atomic_load(x + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s = wave_sum(s);
+            if (lane == 0) __hip_atomic_store(x + r, (xr - s) / dr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): x[r] is in the L2 before its flag is
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane == 0) __hip_atomic_store(done + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---- layout / permutation helpers ----------------------------------------------------------------
 // out (row-major n x k, ld_out) = in (column-major n x k, ld_in), with optional row permutation:
 //   scatter != 0 : out[perm[i], :] = in[i, :]   (ipvec, lib.rs:2151)

@@ -149,8 +149,13 @@ void TriSolver::set_single_use()
     // measured at C2 (7 307 row levels, 47.5 M entries): a level launch costs about 6 us, the programme build about 20 ns per
     // entry; the levels win when they are cheaper by a factor of two.  RSP_SINGLE_USE=0 always keeps the blocked
     // programme, =1 always takes the levels (read per call: the tests run both ways in one process).
+    // RSP_SINGLE_USE=2: rows with flags in one persistent launch (solve_rows_flagged), which needs no programme at all.
     const char *mode = getenv("RSP_SINGLE_USE");
+    single_use_rows_ = false;
+    // Since round 3 that kernel is the default (=2 or unset); 0 and 1 force the two older choices.
+    const bool rows_possible = n_ < INT32_MAX && !G_.placeholder;
     if (mode && (mode[0] == '0' || mode[0] == '1')) single_use_levels_ = mode[0] == '1';
+    else if (rows_possible) single_use_rows_ = true, single_use_levels_ = false;
     else single_use_levels_ = (double)num_row_levels_ * 6e-6 < (double)nnz_ * 1e-8;
     // host half of the level programme right away: analyze_pair() calls this on its worker threads
     if (single_use_levels_ && !have_single_ && !staged_single_) staged_single_.reset(new TriProgramHost(stage_program(kTaskEntriesSingle)));
@@ -758,9 +763,67 @@ void TriSolver::run_single(double *x, hipStream_t stream)
     RSP_HIP(hipGetLastError());
 }
 
+void TriSolver::run_rows(double *x, hipStream_t stream)
+{
+    if (host_values_stale_) throw DeviceError("the row kernel needs the factor's values on the host: refreshed on the device only");
+    if (!rows_.uploaded) {
+        rows_.ptr.upload(G_.ptr);
+        rows_.idx.upload(G_.idx);
+        rows_.val.upload(G_.val);
+        rows_.diag.upload(G_.diag);
+        // rows by dependency level, index order inside a level (a counting sort of level_of_row_); grabs: runs of one level
+        std::vector<i64> at((size_t)num_row_levels_ + 1, 0);
+        for (i64 r = 0; r < n_; ++r) at[(size_t)level_of_row_[(size_t)r] + 1]++;
+        for (i64 l = 0; l < num_row_levels_; ++l) at[(size_t)l + 1] += at[(size_t)l];
+        std::vector<int2> grabs;
+        for (i64 l = 0; l < num_row_levels_; ++l)
+            for (i64 t = at[(size_t)l]; t < at[(size_t)l + 1]; t += dev::kRowsPerGrab)
+                grabs.push_back(int2{(int)t, (int)std::min<i64>(at[(size_t)l + 1], t + dev::kRowsPerGrab)});
+        std::vector<int32_t> order((size_t)n_);
+        {
+            std::vector<i64> fill(at.begin(), at.end() - 1);
+            for (i64 r = 0; r < n_; ++r) order[(size_t)fill[(size_t)level_of_row_[(size_t)r]]++] = (int32_t)r;
+        }
+        rows_.order.upload(order);
+        rows_.ngrabs = (i64)grabs.size();
+        rows_.grabs.resize(std::max<size_t>(1, grabs.size() * sizeof(int2)));
+        if (!grabs.empty()) RSP_HIP(hipMemcpy(rows_.grabs.get(), grabs.data(), grabs.size() * sizeof(int2), hipMemcpyHostToDevice));
+        rows_.done.resize((size_t)n_);
+        rows_.ctl.resize(sizeof(dev::RowsControl));
+        rows_.uploaded = true;
+    }
+    RSP_HIP(hipMemsetAsync(rows_.done.get(), 0, (size_t)n_ * sizeof(int), stream));
+    RSP_HIP(hipMemsetAsync(rows_.ctl.get(), 0, sizeof(dev::RowsControl), stream));
+    hipDeviceProp_t prop;
+    int device = 0;
+    RSP_HIP(hipGetDevice(&device));
+    RSP_HIP(hipGetDeviceProperties(&prop, device));
+    const i64 waves = std::max<i64>(1, std::min<i64>(rows_.ngrabs, (i64)prop.multiProcessorCount * 32));
+    const unsigned spin_limit = (unsigned)env_or("RSP_ROWS_SPIN_LIMIT", 1 << 24);
+    hipLaunchKernelGGL(dev::solve_rows_flagged, dim3((unsigned)waves), dim3(64), 0, stream, rows_.ptr.get(), rows_.idx.get(), rows_.val.get(),
+                       rows_.diag.get(), x, rows_.done.get(), reinterpret_cast<dev::RowsControl *>(rows_.ctl.get()), rows_.order.get(),
+                       reinterpret_cast<const int2 *>(rows_.grabs.get()), (int)rows_.ngrabs, spin_limit);
+    RSP_HIP(hipGetLastError());
+    rows_ran_ = true;
+}
+
+void TriSolver::check_rows_run()
+{
+    if (!rows_ran_) return;
+    rows_ran_ = false;
+    dev::RowsControl c{};
+    RSP_HIP(hipMemcpy(&c, rows_.ctl.get(), sizeof c, hipMemcpyDeviceToHost));
+    if (c.failed)
+        throw DeviceError("solve_rows_flagged: row " + std::to_string(c.stuck_row) + " gave up waiting for row " + std::to_string(c.stuck_source));
+}
+
 void TriSolver::solve_device(double *dX, int layout, i64 ld, i64 nrhs, hipStream_t stream)
 {
     if (nrhs <= 0 || n_ == 0) return;
+    if (nrhs == 1 && (layout == 0 || ld == 1) && single_use_rows_) {
+        run_rows(dX, stream);
+        return;
+    }
     if (nrhs == 1 && (layout == 0 || ld == 1)) {
         // one right-hand side: a column vector is its own row-major n x 1 block.  The blocked programme needs ~170
         // launches per sweep where the plain level programme needs one per dependency level (thousands).
@@ -793,6 +856,7 @@ void TriSolver::solve_host(double *X, i64 ldx, i64 nrhs)
     copy_block_to_device(d.get(), X, n_, ldx, nrhs);
     solve_device(d.get(), 0, n_, nrhs, nullptr);
     RSP_HIP(hipDeviceSynchronize());
+    check_rows_run();
     copy_block_to_host(X, d.get(), n_, ldx, nrhs);
 }
 

@@ -190,11 +190,11 @@ def test_trisolve_single_rhs_vs_oracle(kind, fac):
     assert rel_inf(got, want) <= REL_X
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
 @pytest.mark.parametrize("kind,fac", KINDS)
 def test_one_shot_trisolve_both_programmes(kind, fac, mode, monkeypatch):
-    """One-shot calls choose between the blocked programme and the plain level programme by a cost rule
-    (TriSolver::set_single_use); RSP_SINGLE_USE forces either, and both must give the oracle's result."""
+    """One-shot calls run rows with flags in one persistent launch (solve_rows_flagged, the default and RSP_SINGLE_USE=2);
+    0 forces the blocked programme, 1 the plain level programme; all must give the oracle's result."""
     monkeypatch.setenv("RSP_SINGLE_USE", mode)
     T = factors()[fac]
     b = 2.0 * synth.splitmix64(6, T[0]) - 1.0
@@ -204,7 +204,7 @@ def test_one_shot_trisolve_both_programmes(kind, fac, mode, monkeypatch):
     assert rel_inf(got, want) <= REL_X
 
 
-@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_one_shot_drivers_both_programmes(mode, monkeypatch):
     monkeypatch.setenv("RSP_SINGLE_USE", mode)
     A = synth.laplacian_2d(40, 33)
