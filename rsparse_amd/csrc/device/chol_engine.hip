@@ -1,6 +1,7 @@
 // CholFactor: host-side construction of the panel/update programme, GPU numeric factorisation, and the
 // cholsol solve phase (P, lsolve, ltsolve, P') on the device.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <climits>
 
@@ -23,7 +24,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
     single_use_ = single_use;
     double tmark = now_s();
     auto lap = [&](const char *what) {
-        if (getenv("RSP_TIMING")) fprintf(stderr, "chol analyze: %s %.2fs\n", what, now_s() - tmark);
+        if (getenv("RSP_TIMING")) fprintf(stderr, "chol analyze: %s %.3fs\n", what, now_s() - tmark);
         tmark = now_s();
     };
     n_ = A.n;
@@ -79,6 +80,8 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
                     TriSolver &t = *(k == 0 ? pat_lower_ : pat_upper_);
                     if (pat_ahead_) t.keep_for_refill();
                     pat_status_[k] = t.analyze(Lpat, k);
+                    if (!pat_ahead_ && single_use_ && pat_status_[k] == kOk && TriSolver::rows_wanted() && hipSetDevice(device) == hipSuccess)
+                        t.prepare_rows_pattern();  // one vector, one use: the row kernel's pattern half goes to the device now
                     if (pat_ahead_ && pat_status_[k] == kOk) {
                         t.stage_blocked_pattern();
                         // ... and sends it to the device right away: the first solve finds it there
@@ -92,29 +95,37 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
 
     // ---- where every entry of A lands in L (C(lo,hi) -> L(hi,lo)); for duplicates the LAST one in the
     //      reference's traversal order wins (ereach assigns x[i] = a.x[p], lib.rs:2003) ---------------
+    lap("pattern of L");
     std::vector<i64> Adst(annz_, -1);
     {
-        std::vector<i64> last(n_, -1);
-        for (i64 hi = 0; hi < n_; ++hi) {
-            for (i64 q = C.p[hi]; q < C.p[hi + 1]; ++q) last[C.i[q]] = q;
-            for (i64 q = C.p[hi]; q < C.p[hi + 1]; ++q) {
-                const i64 lo = C.i[q];
-                if (last[lo] != q) continue;  // overwritten by a later duplicate
-                i64 dst;
-                if (lo == hi) {
-                    dst = Lp_[lo];
-                } else {
-                    const i64 *b = Li_.data() + Lp_[lo] + 1, *e = Li_.data() + Lp_[lo + 1];
-                    const i64 *f = std::lower_bound(b, e, hi);
-                    if (f == e || *f != hi) return kBadInput;
-                    dst = f - Li_.data();
+        std::atomic<bool> bad{false};
+        parallel_ranges(n_, 1 << 16, [&](i64 h0, i64 h1) {
+            std::vector<i64> last((size_t)n_, -1);  // (per thread: a column's entries are compared with each other only)
+            for (i64 hi = h0; hi < h1; ++hi) {
+                for (i64 q = C.p[hi]; q < C.p[hi + 1]; ++q) last[C.i[q]] = q;
+                for (i64 q = C.p[hi]; q < C.p[hi + 1]; ++q) {
+                    const i64 lo = C.i[q];
+                    if (last[lo] != q) continue;  // overwritten by a later duplicate
+                    i64 dst;
+                    if (lo == hi) {
+                        dst = Lp_[lo];
+                    } else {
+                        const i64 *b = Li_.data() + Lp_[lo] + 1, *e = Li_.data() + Lp_[lo + 1];
+                        const i64 *f = std::lower_bound(b, e, hi);
+                        if (f == e || *f != hi) {
+                            bad = true;
+                            return;
+                        }
+                        dst = f - Li_.data();
+                    }
+                    Adst[source[q]] = dst;
                 }
-                Adst[source[q]] = dst;
             }
-        }
+        });
+        if (bad) return kBadInput;
     }
 
-    lap("pattern of L and scatter map");
+    lap("scatter map");
     // ---- panels: fundamental supernodes cut to kPanelWidth columns ------------------------------
     const std::vector<i64> super = fundamental_supernodes(S.parent, S.cp);
     nsuper_ = (i64)super.size() - 1;
@@ -265,26 +276,49 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
         std::vector<int32_t> by_target(npairs);
         std::vector<i64> fill(tgt_ptr.begin(), tgt_ptr.end() - 1);
         for (i64 k = 0; k < npairs; ++k) by_target[fill[pairs[k].s]++] = (int32_t)k;
-        std::vector<int32_t> posmap(n_, -1);
+        // target panels are independent of each other: contiguous ranges of them on the host threads, cut by the rows they look up
+        std::vector<i64> work((size_t)npanels_ + 1, 0);
         for (i64 s = 0; s < npanels_; ++s) {
-            if (tgt_ptr[s] == tgt_ptr[s + 1]) continue;
-            const i64 w = c0[s + 1] - c0[s];
-            for (i64 t = 0; t < w; ++t) posmap[c0[s] + t] = (int32_t)t;
-            const i64 *Rs = R(s);
-            for (i64 k = 0; k < prow[s]; ++k) posmap[Rs[k]] = (int32_t)(w + k);
-            for (i64 k = tgt_ptr[s]; k < tgt_ptr[s + 1]; ++k) {
-                const i64 pk = by_target[k];
-                const Pair &p = pairs[pk];
-                const i64 *Rd = R(p.d);
-                for (i64 q = p.q0; q < prow[p.d]; ++q) {
-                    const int32_t pos = posmap[Rd[q]];
-                    // every row below a column of L(:, d) that lies in panel s is a row of panel s (column structure
-                    // of a Cholesky factor); anything else means parent/cp do not describe this pattern
-                    if (pos < 0 || (Rd[q] >= c0[s + 1] && (pos < w || Rs[pos - w] != Rd[q]))) return kBadInput;
-                    rel[(size_t)(rel_off[pk] + (q - p.q0))] = pos;
+            i64 rows = 0;
+            for (i64 k = tgt_ptr[s]; k < tgt_ptr[s + 1]; ++k) rows += rel_off[by_target[k] + 1] - rel_off[by_target[k]];
+            work[(size_t)s + 1] = work[(size_t)s] + rows + (rows ? (c0[s + 1] - c0[s]) + prow[s] : 0);
+        }
+        const i64 threads = std::max<i64>(1, std::min<i64>(host_threads(), work[(size_t)npanels_] >> 20));
+        std::atomic<bool> bad{false};
+        const auto positions = [&](i64 s0, i64 s1) {
+            std::vector<int32_t> posmap((size_t)n_, -1);
+            for (i64 s = s0; s < s1; ++s) {
+                if (tgt_ptr[s] == tgt_ptr[s + 1]) continue;
+                const i64 w = c0[s + 1] - c0[s];
+                for (i64 t = 0; t < w; ++t) posmap[c0[s] + t] = (int32_t)t;
+                const i64 *Rs = R(s);
+                for (i64 k = 0; k < prow[s]; ++k) posmap[Rs[k]] = (int32_t)(w + k);
+                for (i64 k = tgt_ptr[s]; k < tgt_ptr[s + 1]; ++k) {
+                    const i64 pk = by_target[k];
+                    const Pair &p = pairs[pk];
+                    const i64 *Rd = R(p.d);
+                    for (i64 q = p.q0; q < prow[p.d]; ++q) {
+                        const int32_t pos = posmap[Rd[q]];
+                        // every row below a column of L(:, d) that lies in panel s is a row of panel s (column structure
+                        // of a Cholesky factor); anything else means parent/cp do not describe this pattern
+                        if (pos < 0 || (Rd[q] < c0[s + 1] ? (Rd[q] < c0[s] || pos != Rd[q] - c0[s]) : (pos < w || Rs[pos - w] != Rd[q]))) {
+                            bad = true;
+                            return;
+                        }
+                        rel[(size_t)(rel_off[pk] + (q - p.q0))] = pos;
+                    }
                 }
             }
-        }
+        };
+        std::vector<std::thread> pool;
+        std::vector<i64> cut((size_t)threads + 1, npanels_);
+        cut[0] = 0;
+        for (i64 t = 1; t < threads; ++t)
+            cut[(size_t)t] = std::lower_bound(work.begin(), work.end() - 1, work[(size_t)npanels_] * t / threads) - work.begin();
+        for (i64 t = 1; t < threads; ++t) pool.emplace_back(positions, cut[(size_t)t], cut[(size_t)t + 1]);
+        positions(cut[0], cut[1]);
+        for (std::thread &th : pool) th.join();
+        if (bad) return kBadInput;
     }
     lap("tiny tables, row positions");
     // ---- target-owned mode: contributions regrouped by (level, target panel, 16-row tile) -----------------------------
@@ -294,17 +328,30 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
     std::vector<char> group_long;  // some source range of the group has more than 4 columns
     if (grouped) {
         struct Key { int32_t level, s, r16, pair, qa; };
-        std::vector<Key> gen;  // in generation order: pairs ascending, rows ascending
-        for (i64 k = 0; k < npairs; ++k) {
-            const Pair &p = pairs[k];
-            const int32_t *rp = rel.data() + rel_off[k];
-            const i64 cnt = prow[p.d] - p.q0;
-            for (i64 e = 0; e < cnt;) {
-                const int32_t tile = rp[e] >> 4;
-                gen.push_back(Key{p.level, p.s, tile, (int32_t)k, (int32_t)(p.q0 + e)});
-                while (e < cnt && (rp[e] >> 4) == tile) ++e;
+        // in generation order: pairs ascending, rows ascending (counted, then written, both on the host threads)
+        std::vector<i64> gen_off((size_t)npairs + 1, 0);
+        parallel_ranges(npairs, 1 << 14, [&](i64 k0, i64 k1) {
+            for (i64 k = k0; k < k1; ++k) {
+                const int32_t *rp = rel.data() + rel_off[k];
+                const i64 cnt = rel_off[k + 1] - rel_off[k];
+                i64 tiles = cnt > 0;
+                for (i64 e = 1; e < cnt; ++e) tiles += (rp[e] >> 4) != (rp[e - 1] >> 4);
+                gen_off[(size_t)k + 1] = tiles;
             }
-        }
+        });
+        for (i64 k = 0; k < npairs; ++k) gen_off[(size_t)k + 1] += gen_off[(size_t)k];
+        RawVector<Key> gen((size_t)gen_off[(size_t)npairs]);
+        parallel_ranges(npairs, 1 << 14, [&](i64 k0, i64 k1) {
+            for (i64 k = k0; k < k1; ++k) {
+                const Pair &p = pairs[k];
+                const int32_t *rp = rel.data() + rel_off[k];
+                const i64 cnt = rel_off[k + 1] - rel_off[k];
+                Key *out = gen.data() + gen_off[(size_t)k];
+                for (i64 e = 0; e < cnt; ++e)
+                    if (e == 0 || (rp[e] >> 4) != (rp[e - 1] >> 4)) *out++ = Key{p.level, p.s, rp[e] >> 4, (int32_t)k, (int32_t)(p.q0 + e)};
+            }
+        });
+        lap("  tiles: keys");
         if (gen.size() >= (size_t)UINT32_MAX) return kBadInput;
         // order: level, target panel, tile, then generation order (which fixes the order of every sum).  Bucket by
         // level first, then sort (panel, tile, ordinal) triples packed in two words inside each bucket.
@@ -317,7 +364,9 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
             for (size_t x = 0; x < gen.size(); ++x)
                 order[at[gen[x].level]++] = {((uint64_t)(uint32_t)gen[x].s << 32) | (uint32_t)gen[x].r16, (uint32_t)x};
         }
+        lap("  tiles: buckets");
         for (i64 l = 0; l < nlevels_; ++l) parallel_sort(order.begin() + lv_fill[l], order.begin() + lv_fill[l + 1]);
+        lap("  tiles: sort");
         std::vector<Key> keys(gen.size());
         subs.resize(keys.size());
         // the records are independent of each other (host threads); the groups are formed in order afterwards
@@ -346,6 +395,7 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
                 std::memcpy(u.rowmap, map, 16);
             }
         });
+        lap("  tiles: records");
         for (size_t x = 0; x < keys.size(); ++x) {
             const Key &key = keys[x];
             const Pair &p = pairs[key.pair];
@@ -679,6 +729,18 @@ void CholFactor::build_solvers()
         // (anything else -- another engine selected, no recipe -- takes the full analysis with the values on the host)
     }
     pat_ahead_ = false;
+    if (single_use_ && !lower_ && pat_lower_ && pat_upper_ && pat_status_[0] == kOk && pat_status_[1] == kOk && pat_lower_->rows_prepared() &&
+        pat_upper_->rows_prepared()) {
+        // one vector, one use: the row kernel gathers the factor's values on the device; L never visits the host
+        pat_lower_->rows_values_from_device(d_Lp.get(), d_Lx.get(), nullptr);
+        pat_upper_->rows_values_from_device(d_Lp.get(), d_Lx.get(), nullptr);
+        RSP_HIP(hipStreamSynchronize(nullptr));  // the solve that follows may run on any stream
+        if (getenv("RSP_TIMING")) fprintf(stderr, "chol solvers: row kernel, values gathered on the device %.3fs\n", now_s() - t0);
+        lower_ = std::move(pat_lower_);
+        upper_ = std::move(pat_upper_);
+        solvers_stale_ = false;
+        return;
+    }
     std::vector<double> Lx((size_t)lnz_);
     d_Lx.download(Lx.data(), Lx.size());
     const CscView L{n_, n_, Lp_.data(), Li_.data(), Lx.data()};

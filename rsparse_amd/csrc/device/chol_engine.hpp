@@ -71,7 +71,8 @@ class CholFactor {
     i64 n_ = 0, lnz_ = 0, annz_ = 0;
     bool has_pinv_ = false, single_use_ = false, factor_valid_ = false;
     uint64_t pattern_hash_ = 0;
-    std::vector<i64> pinv_, Lp_, Li_;  // host copies (Li_ as the reference stores it)
+    std::vector<i64> pinv_, Lp_;  // host copies
+    RawVector<i64> Li_;           // (as the reference stores it)
     double flops_ = 0.0;
     double factor_ms_ = 0.0;
     i64 npanels_ = 0, nlevels_ = 0, nsuper_ = 0;

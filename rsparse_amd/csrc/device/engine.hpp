@@ -187,6 +187,16 @@ class TriSolver {
     // the flagged row kernel of a single-use handle ran and one of its waits gave up (a defect): call after the stream
     // has been synchronised; throws DeviceError
     void check_rows_run();
+    // The same kernel with the values taken on the device (cholsol's first call on a pattern: the factor never visits the
+    // host).  After a pattern-only analyze(): rows_wanted() says whether a single-use handle would take the row kernel at
+    // all (RSP_SINGLE_USE); prepare_rows_pattern() uploads the pattern half -- pointers, indices, the source position of
+    // every value, rows by level, grabs -- from any thread with the device current, e.g. beside a factorisation;
+    // rows_values_from_device() gathers values and diagonal out of dTx (dTp: the matrix's column pointers on the
+    // device) and makes the handle a single-use one.  Asynchronous on `stream`.  false: nothing was prepared.
+    static bool rows_wanted();
+    void prepare_rows_pattern();
+    bool rows_prepared() const { return rows_.pattern_only; }
+    bool rows_values_from_device(const int64_t *dTp, const double *dTx, hipStream_t stream);
     // NEW VALUES ON THE ANALYSED PATTERN (a refactorisation).  keep_for_refill() before analyze(): the gather form keeps
     // where each of its values comes from and the blocked programme keeps its recipe (BlockProgram::Refill) and a host
     // copy of its coefficients.  refresh_host(T) then pours the values of T (same pattern) into that copy -- host work
@@ -246,13 +256,14 @@ class TriSolver {
     bool single_use_rows_ = false, rows_ran_ = false;
     struct RowsDevice {
         DeviceBuffer<int64_t> ptr;
-        DeviceBuffer<int32_t> idx, order;
+        DeviceBuffer<int32_t> idx, order, src;
         DeviceBuffer<double> val, diag;
         DeviceBuffer<int> done;
         DeviceBuffer<char> ctl, grabs;  // dev::RowsControl, int2 (first, end) positions of each grab
         i64 ngrabs = 0;
-        bool uploaded = false;
+        bool uploaded = false, pattern_only = false;
     } rows_;
+    void upload_rows_schedule();
     void run_rows(double *x, hipStream_t stream);
     std::unique_ptr<BlockProgram> staged_;
     std::unique_ptr<BlockProgram> kept_;  // keep_for_refill(): coef, groups and the recipe of the resident programme

@@ -121,6 +121,19 @@ __global__ __launch_bounds__(256) void solve_level_single(TriArrays T, int task_
 // per lane in entry order, then a fixed butterfly: deterministic, independent of timing.
 constexpr int kRowsPerGrab = 8;
 
+// values of a gather form out of the matrix it was built from, where a factorisation left them on the device: entry e
+// comes from Tx[src[e]], the diagonal of row r from the first (lower storage) or last entry of column r
+__global__ __launch_bounds__(256) void rows_gather_values(const int32_t *__restrict__ src, const double *__restrict__ Tx, double *__restrict__ val,
+                                                          int64_t nnz, const int64_t *__restrict__ Tp, double *__restrict__ diag, int64_t n,
+                                                          int lower_storage)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz || e < n; e += stride) {
+        if (e < nnz) val[e] = Tx[src[e]];
+        if (e < n) diag[e] = Tx[lower_storage ? Tp[e] : Tp[e + 1] - 1];
+    }
+}
+
 struct RowsControl {
     int next;    // next grab
     int failed;  // a wait gave up

@@ -763,33 +763,70 @@ void TriSolver::run_single(double *x, hipStream_t stream)
     RSP_HIP(hipGetLastError());
 }
 
+// rows by dependency level, index order inside a level (a counting sort of level_of_row_); grabs: runs of one level
+void TriSolver::upload_rows_schedule()
+{
+    std::vector<i64> at((size_t)num_row_levels_ + 1, 0);
+    for (i64 r = 0; r < n_; ++r) at[(size_t)level_of_row_[(size_t)r] + 1]++;
+    for (i64 l = 0; l < num_row_levels_; ++l) at[(size_t)l + 1] += at[(size_t)l];
+    std::vector<int2> grabs;
+    for (i64 l = 0; l < num_row_levels_; ++l)
+        for (i64 t = at[(size_t)l]; t < at[(size_t)l + 1]; t += dev::kRowsPerGrab)
+            grabs.push_back(int2{(int)t, (int)std::min<i64>(at[(size_t)l + 1], t + dev::kRowsPerGrab)});
+    std::vector<int32_t> order((size_t)n_);
+    {
+        std::vector<i64> fill(at.begin(), at.end() - 1);
+        for (i64 r = 0; r < n_; ++r) order[(size_t)fill[(size_t)level_of_row_[(size_t)r]]++] = (int32_t)r;
+    }
+    rows_.order.upload(order);
+    rows_.ngrabs = (i64)grabs.size();
+    rows_.grabs.resize(std::max<size_t>(1, grabs.size() * sizeof(int2)));
+    if (!grabs.empty()) RSP_HIP(hipMemcpy(rows_.grabs.get(), grabs.data(), grabs.size() * sizeof(int2), hipMemcpyHostToDevice));
+    rows_.done.resize((size_t)n_);
+    rows_.ctl.resize(sizeof(dev::RowsControl));
+}
+
+bool TriSolver::rows_wanted()
+{
+    const char *mode = getenv("RSP_SINGLE_USE");
+    return !(mode && (mode[0] == '0' || mode[0] == '1'));
+}
+
+void TriSolver::prepare_rows_pattern()
+{
+    if (!G_.placeholder || G_.src.size() != G_.idx.size() || n_ >= INT32_MAX || rows_.uploaded) return;
+    rows_.ptr.upload(G_.ptr);
+    rows_.idx.upload(G_.idx);
+    rows_.src.upload(G_.src);
+    rows_.val.resize(std::max<size_t>(1, G_.idx.size()));
+    rows_.diag.resize((size_t)n_);
+    upload_rows_schedule();
+    rows_.pattern_only = true;
+}
+
+bool TriSolver::rows_values_from_device(const int64_t *dTp, const double *dTx, hipStream_t stream)
+{
+    if (!rows_.pattern_only) return false;
+    const i64 count = std::max<i64>((i64)G_.idx.size(), n_);
+    hipLaunchKernelGGL(dev::rows_gather_values, dim3((unsigned)std::min<i64>((count + 255) / 256, 1 << 20)), dim3(256), 0, stream, rows_.src.get(),
+                       dTx, rows_.val.get(), (int64_t)G_.idx.size(), dTp, rows_.diag.get(), (int64_t)n_, (kind_ == 0 || kind_ == 1) ? 1 : 0);
+    RSP_HIP(hipGetLastError());
+    rows_.uploaded = true;
+    single_use_rows_ = true;
+    single_use_levels_ = false;
+    host_values_stale_ = true;  // the host's gather form holds no values: nothing else can be built from it
+    return true;
+}
+
 void TriSolver::run_rows(double *x, hipStream_t stream)
 {
-    if (host_values_stale_) throw DeviceError("the row kernel needs the factor's values on the host: refreshed on the device only");
     if (!rows_.uploaded) {
+        if (host_values_stale_ || G_.placeholder) throw DeviceError("the row kernel needs the factor's values on the host: refreshed on the device only");
         rows_.ptr.upload(G_.ptr);
         rows_.idx.upload(G_.idx);
         rows_.val.upload(G_.val);
         rows_.diag.upload(G_.diag);
-        // rows by dependency level, index order inside a level (a counting sort of level_of_row_); grabs: runs of one level
-        std::vector<i64> at((size_t)num_row_levels_ + 1, 0);
-        for (i64 r = 0; r < n_; ++r) at[(size_t)level_of_row_[(size_t)r] + 1]++;
-        for (i64 l = 0; l < num_row_levels_; ++l) at[(size_t)l + 1] += at[(size_t)l];
-        std::vector<int2> grabs;
-        for (i64 l = 0; l < num_row_levels_; ++l)
-            for (i64 t = at[(size_t)l]; t < at[(size_t)l + 1]; t += dev::kRowsPerGrab)
-                grabs.push_back(int2{(int)t, (int)std::min<i64>(at[(size_t)l + 1], t + dev::kRowsPerGrab)});
-        std::vector<int32_t> order((size_t)n_);
-        {
-            std::vector<i64> fill(at.begin(), at.end() - 1);
-            for (i64 r = 0; r < n_; ++r) order[(size_t)fill[(size_t)level_of_row_[(size_t)r]]++] = (int32_t)r;
-        }
-        rows_.order.upload(order);
-        rows_.ngrabs = (i64)grabs.size();
-        rows_.grabs.resize(std::max<size_t>(1, grabs.size() * sizeof(int2)));
-        if (!grabs.empty()) RSP_HIP(hipMemcpy(rows_.grabs.get(), grabs.data(), grabs.size() * sizeof(int2), hipMemcpyHostToDevice));
-        rows_.done.resize((size_t)n_);
-        rows_.ctl.resize(sizeof(dev::RowsControl));
+        upload_rows_schedule();
         rows_.uploaded = true;
     }
     RSP_HIP(hipMemsetAsync(rows_.done.get(), 0, (size_t)n_ * sizeof(int), stream));

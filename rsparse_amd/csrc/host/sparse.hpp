@@ -5,11 +5,36 @@
 #pragma once
 #include <climits>
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 namespace rsp {
 
 using i64 = int64_t;
+
+// A vector whose resize() leaves new elements UNINITIALISED: for large index arrays that are written exactly once, by
+// several host threads -- value-initialising 400 MB on one thread costs more than filling it (every fresh page faults in
+// on that thread).
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U *p)
+    {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <class T>
+using RawVector = std::vector<T, DefaultInitAllocator<T>>;
 
 // borrowed CSC view == the arrays of rsparse::data::Sprs<f64> (data.rs:194-208)
 struct CscView {
@@ -71,7 +96,7 @@ Symbolic symbolic_lu(const CscView &A, int order);
 // diagonal first in each column, remaining rows strictly ascending.  Li has cp[n] entries.
 // Returns false if cp disagrees with the pattern that parent generates (a corrupt Symb).
 bool cholesky_pattern(const CscView &C_upper, const std::vector<i64> &parent, const std::vector<i64> &cp,
-                      std::vector<i64> &Li);
+                      RawVector<i64> &Li);
 
 // supernode partition of a Cholesky factor: super_start has nsuper+1 entries; consecutive columns j, j+1
 // share a supernode when parent[j] == j+1 and count[j] == count[j+1] + 1.

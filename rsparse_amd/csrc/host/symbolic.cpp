@@ -5,7 +5,9 @@
 // subtrees directly (one pass that counts, one that fills) instead of the skeleton-matrix algorithm the
 // reference uses (lib.rs:1797-1897); the fill pass is needed anyway to hand the pattern to the GPU.
 #include <algorithm>
+#include <thread>
 
+#include "parallel.hpp"
 #include "sparse.hpp"
 
 namespace rsp {
@@ -119,24 +121,138 @@ Symbolic symbolic_lu(const CscView &A, int order)
     return S;
 }
 
-bool cholesky_pattern(const CscView &C, const std::vector<i64> &parent, const std::vector<i64> &cp, std::vector<i64> &Li)
+// Column structures through the supernodes instead of row by row (which is 47 M scattered appends at C2: the slowest
+// stage of a Cholesky analysis).  With parent the elimination tree of C,
+//     struct(j) = {j}  U  {k > j : C(j,k) != 0}  U  union over the children c of j of struct(c) \ {c},
+// and inside a supernode (parent[j] == j + 1, count[j + 1] == count[j] - 1) struct(j + 1) = struct(j) \ {j}.  So only the
+// FIRST column of every supernode is merged (from its children's lists, which are tails of first columns already done:
+// the sum of those tails is a small fraction of nnz(L)); the other columns are tails of it, copied on the host threads.
+// Everything the partition assumes is verified on the way -- parent against the elimination tree of C, every merged
+// list against cp, every other contribution to a later column of a supernode against the first column's list -- so a
+// Symb that does not describe this matrix is refused, as before.
+bool cholesky_pattern(const CscView &C, const std::vector<i64> &parent, const std::vector<i64> &cp, RawVector<i64> &Li)
 {
     const i64 n = C.n;
-    Li.assign(cp[n], 0);
-    std::vector<i64> fill(cp.begin(), cp.end() - 1), mark(n, -1);
-    bool ok = true;
-    // rows are appended in increasing k, and the diagonal of column k is written when row k is finished, i.e.
-    // before any later row can append to column k: diagonal first, then ascending rows (lib.rs:316-319, 329-332)
-    for (i64 k = 0; k < n && ok; ++k) {
-        for_each_in_row_subtree(C, parent, k, mark, [&](i64 col) {
-            if (fill[col] < cp[col + 1]) Li[fill[col]++] = k;
-            else ok = false;
-        });
-        if (fill[k] != cp[k]) ok = false;  // the diagonal must be the first entry of its column
-        else Li[fill[k]++] = k;
+    if ((i64)parent.size() != n || (i64)cp.size() != n + 1 || cp[0] != 0) return false;
+    for (i64 j = 0; j < n; ++j)
+        if (cp[j + 1] <= cp[j] || cp[j + 1] - cp[j] > n - j) return false;
+    if (n >= INT32_MAX) return false;
+    if (parent != elimination_tree(C)) return false;
+    // rows of C (upper triangle): row j lists the k > j with C(j,k) != 0
+    std::vector<i64> rp((size_t)n + 1, 0);
+    for (i64 k = 0; k < n; ++k)
+        for (i64 e = C.p[k]; e < C.p[k + 1]; ++e) {
+            if (C.i[e] < 0 || C.i[e] > k) return false;
+            if (C.i[e] < k) rp[(size_t)C.i[e] + 1]++;
+        }
+    for (i64 j = 0; j < n; ++j) rp[(size_t)j + 1] += rp[(size_t)j];
+    std::vector<int32_t> rk((size_t)rp[(size_t)n]);
+    {
+        std::vector<i64> at(rp.begin(), rp.end() - 1);
+        for (i64 k = 0; k < n; ++k)
+            for (i64 e = C.p[k]; e < C.p[k + 1]; ++e)
+                if (C.i[e] < k) rk[(size_t)at[(size_t)C.i[e]]++] = (int32_t)k;
     }
-    for (i64 j = 0; j < n && ok; ++j) ok = fill[j] == cp[j + 1];
-    return ok;
+    // children lists (ascending)
+    std::vector<int32_t> child_head((size_t)n, -1), child_next((size_t)n, -1);
+    for (i64 j = n - 1; j >= 0; --j)
+        if (parent[(size_t)j] >= 0) {
+            child_next[(size_t)j] = child_head[(size_t)parent[(size_t)j]];
+            child_head[(size_t)parent[(size_t)j]] = (int32_t)j;
+        }
+    Li.resize((size_t)cp[(size_t)n]);  // (uninitialised)
+    // fresh pages fault in on whoever touches them first: on all threads at once, not one by one in the merge below
+    parallel_ranges((i64)Li.size(), (i64)1 << 22, [&](i64 b, i64 e) {
+        for (i64 k = b; k < e; k += 512) Li[(size_t)k] = 0;
+    });
+    std::vector<int32_t> first_of((size_t)n);   // first column of the supernode of column j
+    std::vector<int32_t> mark((size_t)n, -1);   // mark[r] == f: r is in struct(f), f the first column being worked on
+    std::vector<i64> list;
+    // the rows below the diagonal of a finished column c: a tail of its supernode's first column
+    const auto below = [&](i64 c, const i64 *&b, const i64 *&e) {
+        const i64 f = first_of[(size_t)c];
+        b = Li.data() + cp[(size_t)f] + (c - f) + 1;
+        e = Li.data() + cp[(size_t)f + 1];
+    };
+    for (i64 f = 0; f < n;) {
+        i64 last = f;
+        while (last + 1 < n && parent[(size_t)last] == last + 1 &&
+               cp[(size_t)last + 1] - cp[(size_t)last] == cp[(size_t)last + 2] - cp[(size_t)last + 1] + 1)
+            ++last;
+        for (i64 j = f; j <= last; ++j) first_of[(size_t)j] = (int32_t)f;
+        // struct(f): every source is ascending, so what it adds is an ascending run; runs that do not simply continue the
+        // list are merged in (a column usually has one child that brings nearly everything)
+        list.clear();
+        mark[(size_t)f] = (int32_t)f;
+        size_t runs = 0;
+        bool ascending = true;
+        const auto close_run = [&](size_t start) {
+            if (start == list.size()) return;
+            ++runs;
+            if (start > 0 && list[start] < list[start - 1]) {
+                if (runs <= 8) std::inplace_merge(list.begin(), list.begin() + (std::ptrdiff_t)start, list.end());
+                else ascending = false;
+            }
+        };
+        for (int32_t c = child_head[(size_t)f]; c >= 0; c = child_next[(size_t)c]) {
+            const i64 *b, *e;
+            below(c, b, e);
+            const size_t start = list.size();
+            for (; b < e; ++b)
+                if (mark[(size_t)*b] != f) {
+                    mark[(size_t)*b] = (int32_t)f;
+                    list.push_back(*b);
+                }
+            close_run(start);
+        }
+        {
+            const size_t start = list.size();
+            for (i64 e = rp[(size_t)f]; e < rp[(size_t)f + 1]; ++e) {
+                const int32_t k = rk[(size_t)e];
+                if (mark[(size_t)k] != f) {
+                    mark[(size_t)k] = (int32_t)f;
+                    list.push_back(k);
+                }
+            }
+            close_run(start);
+        }
+        if ((i64)list.size() != cp[(size_t)f + 1] - cp[(size_t)f] - 1) return false;
+        if (!ascending) std::sort(list.begin(), list.end());
+        i64 *out = Li.data() + cp[(size_t)f];
+        out[0] = f;
+        std::copy(list.begin(), list.end(), out + 1);
+        // the later columns of the supernode: their own entries of C and their other children add nothing new
+        for (i64 j = f + 1; j <= last; ++j) {
+            if (out[j - f] != j) return false;
+            for (i64 e = rp[(size_t)j]; e < rp[(size_t)j + 1]; ++e)
+                if (mark[(size_t)rk[(size_t)e]] != f) return false;
+            for (int32_t c = child_head[(size_t)j]; c >= 0; c = child_next[(size_t)c]) {
+                if (c == j - 1) continue;
+                const i64 *b, *e;
+                below(c, b, e);
+                for (; b < e; ++b)
+                    if (mark[(size_t)*b] != f) return false;
+            }
+        }
+        f = last + 1;
+    }
+    // the tails: column j of a supernode that starts at f is struct(f) without its first j - f rows; threads by entries
+    const i64 threads = std::max<i64>(1, std::min<i64>(host_threads(), cp[(size_t)n] >> 18));
+    std::vector<i64> cut((size_t)threads + 1, n);
+    cut[0] = 0;
+    for (i64 t = 1; t < threads; ++t)
+        cut[(size_t)t] = std::lower_bound(cp.begin(), cp.end() - 1, cp[(size_t)n] * t / threads) - cp.begin();
+    const auto tails = [&](i64 j0, i64 j1) {
+        for (i64 j = j0; j < j1; ++j) {
+            const i64 f = first_of[(size_t)j];
+            if (f != j) std::copy(Li.data() + cp[(size_t)f] + (j - f), Li.data() + cp[(size_t)f + 1], Li.data() + cp[(size_t)j]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (i64 t = 1; t < threads; ++t) pool.emplace_back(tails, cut[(size_t)t], cut[(size_t)t + 1]);
+    tails(cut[0], cut[1]);
+    for (std::thread &th : pool) th.join();
+    return true;
 }
 
 std::vector<i64> fundamental_supernodes(const std::vector<i64> &parent, const std::vector<i64> &cp)
