@@ -839,7 +839,7 @@ void TriSolver::run_rows(double *x, hipStream_t stream)
     const unsigned spin_limit = (unsigned)env_or("RSP_ROWS_SPIN_LIMIT", 1 << 24);
     hipLaunchKernelGGL(dev::solve_rows_flagged, dim3((unsigned)waves), dim3(64), 0, stream, rows_.ptr.get(), rows_.idx.get(), rows_.val.get(),
                        rows_.diag.get(), x, rows_.done.get(), reinterpret_cast<dev::RowsControl *>(rows_.ctl.get()), rows_.order.get(),
-                       reinterpret_cast<const int2 *>(rows_.grabs.get()), (int)rows_.ngrabs, spin_limit);
+                       reinterpret_cast<const int2 *>(rows_.grabs.get()), (int)rows_.ngrabs, spin_limit, G_.descending ? 1 : 0);
     RSP_HIP(hipGetLastError());
     rows_ran_ = true;
 }
