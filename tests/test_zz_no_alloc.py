@@ -35,9 +35,20 @@ def test_noalloc_entry_point_matches_the_allocating_one():
                 assert info["scratch_rows"] > 0  # the kernels really use the scratch buffer
                 first = False
             Xn = torch.tensor(B, device="cuda:0")
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]  # hipMemGetInfo: the device's free bytes, whoever allocates
             h.solve_dev_noalloc(Xn.data_ptr(), nrhs, nrhs, stream)
             torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] >= free_before  # nothing was allocated by the call
             assert torch.equal(Xa, Xn)  # bit for bit
+            # a block with a row stride larger than its width: the columns beyond nrhs are not touched
+            ld = nrhs + 8
+            Xw = torch.full((n, ld), 7.25, dtype=torch.float64, device="cuda:0")
+            Xw[:, :nrhs] = torch.tensor(B, device="cuda:0")
+            h.solve_dev_noalloc(Xw.data_ptr(), ld, nrhs, stream)
+            torch.cuda.synchronize()
+            assert torch.equal(Xw[:, :nrhs], Xa)
+            assert bool((Xw[:, nrhs:] == 7.25).all())
             want = orc.trisolve(name, L, B[:, 3].copy())
             got = Xn[:, 3].cpu().numpy()
             assert np.max(np.abs(got - want)) / np.max(np.abs(want)) <= 1e-8
