@@ -1694,10 +1694,15 @@ int rsp_lusol_f64(const rsp_csc_f64 *A, double *b, int8_t order, double tol)
     }
     rsp_symb *S = nullptr;
     rsp_lu *N = nullptr;
+    const double t0 = now_s();
     int st = rsp_sqr_lu(A, order, &S);               // ordering (host)
+    const double t1 = now_s();
     if (st == RSP_OK) st = rsp_lu_f64(A, S, tol, &N);  // numeric LU: GPU when the diagonal pivots hold, else host; same bits
+    const double t2 = now_s();
     if (st == RSP_OK) N->single_use = true;
     if (st == RSP_OK) st = rsp_lu_solve_f64(N, S, b, A->n, 1);  // lsolve + usolve (GPU)
+    if (getenv("RSP_TIMING"))
+        fprintf(stderr, "lusol: sqr %.2fs, lu %.2fs (%s), solve (analysis + solve) %.2fs\n", t1 - t0, t2 - t1, N && N->device ? "device" : "host", now_s() - t2);
     if (st == RSP_OK && may_insert && N->device) {
         // keep the factorisation's device half and its patterns for the next call on this pattern
         CholCache &C = chol_cache();

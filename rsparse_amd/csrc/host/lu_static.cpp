@@ -9,13 +9,18 @@
 // when it fails anywhere the caller falls back to sparse_lu.
 //
 // The search costs as many steps as the numeric factorisation costs multiply-subtracts (the reach of column k walks every
-// entry of every column of L it touches) and is what a GPU factorisation spends most of its time in.  It stays
-// sequential: running columns on several threads in ascending order, each waiting for the patterns it needs (the scheme
-// of the device kernel), was measured and is SLOWER than one thread on every test matrix (banded 50 000: 0.73 s on one
-// thread, 1.09 s on eight) -- a column's search dives to the most recent columns first and stalls at once.  What did
-// pay is 32-bit storage of the patterns while they are searched (1.7 times faster than the 64-bit search of host/lu.cpp).
+// entry of every column of L it touches) and is what a GPU factorisation spends most of its time in.  One column's search
+// is sequential by nature, and the reference's ORDER of a reach (which fixes the order of every sum) only comes out of that
+// search; but columns in different subtrees of the elimination tree of B + B' (B = A in pivot coordinates) never meet, so
+// the columns are searched on the host threads in the order of that tree's levels, a column starting when its children
+// are complete (a counter per column) -- the scheme of lu_columns and of the one-shot row kernel.  Two earlier attempts
+// with the columns in ASCENDING order (each waiting for the patterns it met) were slower than one thread: consecutive
+// columns are one chain.  Patterns are searched in 32-bit storage (1.7 times faster than the 64-bit search of host/lu.cpp).
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <memory>
+#include <thread>
 
 #include "parallel.hpp"
 #include "sparse.hpp"
@@ -52,6 +57,122 @@ struct Column {
     int32_t llen = 0, ulen = 0;
 };
 
+// One thread's search state; column(k) is the reference's reach of column k with every pivot known in advance.
+struct Searcher {
+    const CscView &A;
+    const i64 *q;
+    const std::vector<int32_t> &col_of_row;
+    Column *cols;
+    std::vector<int32_t> &level;
+    const std::atomic<uint8_t> *done;  // null: sequential (every earlier column is complete)
+    std::atomic<bool> *failed;
+    std::vector<int32_t> order, stack, resume, seen, dup;
+    Arena arena;  // (the patterns live in it until they are assembled)
+
+    Searcher(const CscView &A_, const i64 *q_, const std::vector<int32_t> &cr, Column *c, std::vector<int32_t> &lv, const std::atomic<uint8_t> *d,
+             std::atomic<bool> *f)
+        : A(A_), q(q_), col_of_row(cr), cols(c), level(lv), done(d), failed(f), order((size_t)A_.n), stack((size_t)A_.n), resume((size_t)A_.n),
+          seen((size_t)A_.n, -1), dup((size_t)A_.n, -1)
+    {
+    }
+
+    // an earlier column met by the search must be complete: by construction it is (a descendant in the elimination tree);
+    // should that ever not hold, wait for it -- bounded -- rather than read half a pattern
+    bool complete(int32_t jcol) const
+    {
+        if (!done || done[jcol].load(std::memory_order_acquire)) return true;
+        for (i64 spins = 0; spins < ((i64)1 << 26); ++spins) {
+            if (done[jcol].load(std::memory_order_acquire)) return true;
+            if (failed->load(std::memory_order_relaxed)) return false;
+            std::this_thread::yield();
+        }
+        return false;
+    }
+
+    bool column(i64 k)
+    {
+        const i64 n = A.n;
+        const i64 col = q ? q[k] : k;
+        // reach of A(:,col) through the columns of L that exist when column k is factored (columns < k): rows are ORIGINAL
+        // row numbers, as in lu.cpp; row j is pivotal iff its column col_of_row[j] < k, and then that column of L continues
+        // the search
+        i64 top = n;
+        for (i64 e = A.p[col]; e < A.p[col + 1]; ++e) {
+            const int32_t root = (int32_t)A.i[e];
+            if (seen[(size_t)root] == k) continue;  // (reached already, or a duplicate: checked below)
+            i64 depth = 0;
+            stack[0] = root;
+            while (depth >= 0) {
+                const int32_t j = stack[(size_t)depth];
+                const int32_t jcol = col_of_row[(size_t)j];
+                const int32_t *list = nullptr;
+                int32_t end = 0;
+                if (seen[(size_t)j] != k) {
+                    seen[(size_t)j] = (int32_t)k;
+                    resume[(size_t)depth] = 0;
+                    if (jcol < k && !complete(jcol)) return false;
+                }
+                if (jcol < k) {
+                    const Column &c = cols[(size_t)jcol];
+                    list = c.l;
+                    end = c.llen;
+                }
+                bool finished = true;
+                for (int32_t p = resume[(size_t)depth]; p < end; ++p) {
+                    const int32_t i = list[p];
+                    if (seen[(size_t)i] == k) continue;
+                    resume[(size_t)depth] = p;
+                    stack[(size_t)++depth] = i;
+                    finished = false;
+                    break;
+                }
+                if (finished) {
+                    --depth;
+                    order[(size_t)--top] = j;
+                }
+            }
+        }
+        // duplicate row indices inside the column of A: the reference keeps the LAST value (x[i] = a.x[p] in order); the device
+        // scatters a column's entries in parallel, so such matrices stay on the host
+        bool good = true;
+        for (i64 e = A.p[col]; e < A.p[col + 1] && good; ++e) {
+            if (dup[(size_t)A.i[e]] == k) good = false;
+            dup[(size_t)A.i[e]] = (int32_t)k;
+        }
+        i64 ulen = 1, llen = 1;
+        bool diagonal_reached = false;
+        for (i64 t = top; t < n; ++t) {
+            const int32_t i = order[(size_t)t];
+            if (col_of_row[(size_t)i] < k) ++ulen;
+            else if (i == col) diagonal_reached = true;
+            else ++llen;
+        }
+        if (!good || !diagonal_reached) return false;
+        int32_t *u = arena.take((size_t)ulen), *l = arena.take((size_t)llen);
+        i64 un = 0, ln = 0;
+        int32_t lev = 0;
+        l[ln++] = (int32_t)col;  // L(k,k) first
+        for (i64 t = top; t < n; ++t) {
+            const int32_t i = order[(size_t)t];
+            const int32_t c = col_of_row[(size_t)i];
+            if (c < k) {
+                u[un++] = c;
+                lev = std::max(lev, level[(size_t)c] + 1);
+            } else if (i != col) {
+                l[ln++] = i;
+            }
+        }
+        u[un++] = (int32_t)k;  // U(k,k) last
+        level[(size_t)k] = lev;
+        Column &mine = cols[(size_t)k];
+        mine.l = l;
+        mine.u = u;
+        mine.llen = (int32_t)llen;
+        mine.ulen = (int32_t)ulen;
+        return true;
+    }
+};
+
 }  // namespace
 
 // out.L / out.U: p and i final, x sized and zero; out.pinv; level[k] = 0 for a column that depends on no other, else
@@ -72,87 +193,94 @@ bool lu_static_pattern(const CscView &A, const i64 *q, LuFactors &out, std::vect
         if (A.i[e] < 0 || A.i[e] >= n) return false;
     level.assign((size_t)n, 0);
     std::unique_ptr<Column[]> cols(new Column[(size_t)n]);
-    Arena arena;  // (the patterns live in it until they are assembled below)
-    {
-        std::vector<int32_t> order((size_t)n), stack((size_t)n), resume((size_t)n), seen((size_t)n, -1), dup((size_t)n, -1);
+    std::atomic<bool> failed{false};
+    const char *env = std::getenv("RSP_LU_SEARCH_THREADS");
+    const i64 threads = std::max<i64>(1, std::min<i64>(env && *env ? std::atoll(env) : host_threads(), n / 2048));
+    std::vector<std::unique_ptr<Searcher>> searchers;  // (they own the arenas: alive until the patterns are assembled)
+    if (threads <= 1) {
+        searchers.emplace_back(new Searcher(A, q, col_of_row, cols.get(), level, nullptr, &failed));
+        for (i64 k = 0; k < n; ++k)
+            if (!searchers[0]->column(k)) return false;
+    } else {
+        // elimination tree of B + B' (B = A in pivot coordinates: column k, row col_of_row[row]), Liu's algorithm
+        std::vector<i64> lp((size_t)n + 1, 0);
         for (i64 k = 0; k < n; ++k) {
             const i64 col = q ? q[k] : k;
-            // reach of A(:,col) through the columns of L that exist when column k is factored (columns < k): rows are ORIGINAL
-            // row numbers, as in lu.cpp; row j is pivotal iff its column col_of_row[j] < k, and then that column of L continues
-            // the search
-            i64 top = n;
             for (i64 e = A.p[col]; e < A.p[col + 1]; ++e) {
-                const int32_t root = (int32_t)A.i[e];
-                if (seen[(size_t)root] == k) continue;  // (reached already, or a duplicate: checked below)
-                i64 depth = 0;
-                stack[0] = root;
-                while (depth >= 0) {
-                    const int32_t j = stack[(size_t)depth];
-                    const int32_t jcol = col_of_row[(size_t)j];
-                    const int32_t *list = nullptr;
-                    int32_t end = 0;
-                    if (jcol < k) {
-                        const Column &c = cols[(size_t)jcol];
-                        list = c.l;
-                        end = c.llen;
-                    }
-                    if (seen[(size_t)j] != k) {
-                        seen[(size_t)j] = (int32_t)k;
-                        resume[(size_t)depth] = 0;
-                    }
-                    bool finished = true;
-                    for (int32_t p = resume[(size_t)depth]; p < end; ++p) {
-                        const int32_t i = list[p];
-                        if (seen[(size_t)i] == k) continue;
-                        resume[(size_t)depth] = p;
-                        stack[(size_t)++depth] = i;
-                        finished = false;
-                        break;
-                    }
-                    if (finished) {
-                        --depth;
-                        order[(size_t)--top] = j;
-                    }
-                }
+                const i64 r = col_of_row[(size_t)A.i[e]];
+                if (r != k) lp[(size_t)std::max(r, k) + 1]++;
             }
-            // duplicate row indices inside the column of A: the reference keeps the LAST value (x[i] = a.x[p] in order); the device
-            // scatters a column's entries in parallel, so such matrices stay on the host
-            bool good = true;
-            for (i64 e = A.p[col]; e < A.p[col + 1] && good; ++e) {
-                if (dup[(size_t)A.i[e]] == k) good = false;
-                dup[(size_t)A.i[e]] = (int32_t)k;
-            }
-            i64 ulen = 1, llen = 1;
-            bool diagonal_reached = false;
-            for (i64 t = top; t < n; ++t) {
-                const int32_t i = order[(size_t)t];
-                if (col_of_row[(size_t)i] < k) ++ulen;
-                else if (i == col) diagonal_reached = true;
-                else ++llen;
-            }
-            if (!good || !diagonal_reached) return false;
-            int32_t *u = arena.take((size_t)ulen), *l = arena.take((size_t)llen);
-            i64 un = 0, ln = 0;
-            int32_t lev = 0;
-            l[ln++] = (int32_t)col;  // L(k,k) first
-            for (i64 t = top; t < n; ++t) {
-                const int32_t i = order[(size_t)t];
-                const int32_t c = col_of_row[(size_t)i];
-                if (c < k) {
-                    u[un++] = c;
-                    lev = std::max(lev, level[(size_t)c] + 1);
-                } else if (i != col) {
-                    l[ln++] = i;
-                }
-            }
-            u[un++] = (int32_t)k;  // U(k,k) last
-            level[(size_t)k] = lev;
-            Column &mine = cols[(size_t)k];
-            mine.l = l;
-            mine.u = u;
-            mine.llen = (int32_t)llen;
-            mine.ulen = (int32_t)ulen;
         }
+        for (i64 k = 0; k < n; ++k) lp[(size_t)k + 1] += lp[(size_t)k];
+        std::vector<int32_t> lo((size_t)lp[(size_t)n]);
+        {
+            std::vector<i64> at(lp.begin(), lp.end() - 1);
+            for (i64 k = 0; k < n; ++k) {
+                const i64 col = q ? q[k] : k;
+                for (i64 e = A.p[col]; e < A.p[col + 1]; ++e) {
+                    const i64 r = col_of_row[(size_t)A.i[e]];
+                    if (r != k) lo[(size_t)at[(size_t)std::max(r, k)]++] = (int32_t)std::min(r, k);
+                }
+            }
+        }
+        std::vector<int32_t> parent((size_t)n, -1), ancestor((size_t)n, -1);
+        for (i64 k = 0; k < n; ++k)
+            for (i64 e = lp[(size_t)k]; e < lp[(size_t)k + 1]; ++e) {
+                int32_t i = lo[(size_t)e];
+                while (i != -1 && i < k) {
+                    const int32_t up = ancestor[(size_t)i];
+                    ancestor[(size_t)i] = (int32_t)k;
+                    if (up == -1) parent[(size_t)i] = (int32_t)k;
+                    i = up;
+                }
+            }
+        // columns by the height of their subtree (children have smaller numbers), ascending inside a level
+        std::vector<int32_t> height((size_t)n, 0);
+        std::unique_ptr<std::atomic<int32_t>[]> pending(new std::atomic<int32_t>[(size_t)n]);
+        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[(size_t)n]);
+        for (i64 k = 0; k < n; ++k) {
+            pending[(size_t)k].store(0, std::memory_order_relaxed);
+            done[(size_t)k].store(0, std::memory_order_relaxed);
+        }
+        i64 heights = 0;
+        for (i64 k = 0; k < n; ++k) {
+            const int32_t p = parent[(size_t)k];
+            if (p >= 0) {
+                height[(size_t)p] = std::max(height[(size_t)p], height[(size_t)k] + 1);
+                pending[(size_t)p].fetch_add(1, std::memory_order_relaxed);
+            }
+            heights = std::max<i64>(heights, height[(size_t)k] + 1);
+        }
+        std::vector<i64> at((size_t)heights + 1, 0);
+        for (i64 k = 0; k < n; ++k) at[(size_t)height[(size_t)k] + 1]++;
+        for (i64 h = 0; h < heights; ++h) at[(size_t)h + 1] += at[(size_t)h];
+        std::vector<int32_t> sequence((size_t)n);
+        for (i64 k = 0; k < n; ++k) sequence[(size_t)at[(size_t)height[(size_t)k]]++] = (int32_t)k;
+        std::atomic<i64> next{0};
+        for (i64 t = 0; t < threads; ++t) searchers.emplace_back(new Searcher(A, q, col_of_row, cols.get(), level, done.get(), &failed));
+        const auto work = [&](Searcher &S) {
+            for (;;) {
+                const i64 t = next.fetch_add(1, std::memory_order_relaxed);
+                if (t >= n || failed.load(std::memory_order_relaxed)) return;
+                const i64 k = sequence[(size_t)t];
+                // the children were taken earlier (lower height) by threads that are running: this wait ends
+                for (i64 spins = 0; pending[(size_t)k].load(std::memory_order_acquire) != 0; ++spins) {
+                    if (failed.load(std::memory_order_relaxed)) return;
+                    if (spins > 64) std::this_thread::yield();
+                }
+                if (!S.column(k)) {
+                    failed.store(true, std::memory_order_relaxed);
+                    return;
+                }
+                done[(size_t)k].store(1, std::memory_order_release);
+                if (parent[(size_t)k] >= 0) pending[(size_t)parent[(size_t)k]].fetch_sub(1, std::memory_order_acq_rel);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (i64 t = 1; t < threads; ++t) pool.emplace_back(work, std::ref(*searchers[(size_t)t]));
+        work(*searchers[0]);
+        for (std::thread &th : pool) th.join();
+        if (failed.load()) return false;
     }
     // assemble: column pointers, then the indices (row indices of L in pivot order: every row is the pivot of col_of_row[row])
     Csc &L = out.L, &U = out.U;
