@@ -123,6 +123,38 @@ def test_lu_static_pattern_refuses_what_the_device_cannot_do():
         rs.lu_static_pattern(D, rs.sqr(D, -1))
 
 
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_lu_static_pattern_does_not_depend_on_the_thread_count(threads, monkeypatch):
+    """The search runs on the host threads by elimination-tree levels from 4 096 columns on (RSP_LU_SEARCH_THREADS): pinv, the
+    patterns in the reference's storage order and the dependency depth equal the oracle's lu whatever the thread count."""
+    monkeypatch.setenv("RSP_LU_SEARCH_THREADS", threads)
+    for A, order in ((synth.banded_unsymmetric(12000), 1), (synth.laplacian_2d(80), 1), (synth.banded_unsymmetric(9000), -1)):
+        st, want = orc.lu(A, order, 1.0)
+        assert st == orc.OK
+        assert np.array_equal(want["pinv"][want["q"]], np.arange(A[1])), "test matrix must keep its diagonal pivots"
+        N, depth = rs.lu_static_pattern(A, rs.sqr(A, order))
+        assert N.pinv.tolist() == want["pinv"].tolist()
+        for got, ref in ((N.l, want["L"]), (N.u, want["U"])):
+            assert np.array_equal(got.p, ref[2])
+            assert np.array_equal(got.i.astype(np.int64), ref[3])
+        if threads == "1":
+            test_lu_static_pattern_does_not_depend_on_the_thread_count.depth = getattr(
+                test_lu_static_pattern_does_not_depend_on_the_thread_count, "depth", {})
+            test_lu_static_pattern_does_not_depend_on_the_thread_count.depth[(A[1], order)] = depth
+        else:
+            assert depth == test_lu_static_pattern_does_not_depend_on_the_thread_count.depth[(A[1], order)]
+    # a duplicate entry inside a column far from the first one: every thread stops, the call refuses
+    m, n, p, i, x = synth.banded_unsymmetric(9000)
+    j = 7000
+    i2 = np.insert(i, p[j + 1], i[p[j]])
+    x2 = np.insert(x, p[j + 1], 0.5)
+    p2 = p.copy()
+    p2[j + 1:] += 1
+    B = (m, n, p2, i2, x2)
+    with pytest.raises(rs.DeviceError):
+        rs.lu_static_pattern(B, rs.sqr(B, -1))
+
+
 def test_lu_no_pivot_error():
     A = rs.Sprs.from_vec([[1.0, 2.0], [2.0, 4.0]])  # singular
     with pytest.raises(rs.NoPivot):
