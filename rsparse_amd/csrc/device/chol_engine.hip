@@ -187,36 +187,58 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
             const i64 s = first_panel[k];
             if (first_panel[k + 1] - s == 1 && c0[s + 1] - c0[s] <= 4 && (c0[s + 1] - c0[s]) + prow[s] <= 16) tiny[s] = 1;
         }
-    for (i64 k = 0; k < nsuper_; ++k) {
-        const i64 sc = super[k], se = super[k + 1];
-        for (i64 d = first_panel[k]; d < first_panel[k + 1]; ++d) {
-            if (tiny[d] && !grouped) continue;  // the tiny kernel applies its own updates, except in target-owned mode
-            const i64 *Rd = R(d);
-            const i64 rd = prow[d];
-            const i64 blk0 = first_panel[k] + (d - first_panel[k]) / bp * bp;      // first panel of d's block
-            const i64 blk1 = std::min<i64>(blk0 + bp, first_panel[k + 1]);          // one past its last panel
-            const bool last_in_block = d + 1 == blk1, last = d + 1 == first_panel[k + 1];
-            const i64 block_end_col = c0[blk1];  // == se for the last block
-            for (i64 q = 0; q < rd;) {
-                const i64 row = Rd[q];
-                Pair p{(int32_t)d, panel_of[row], (int32_t)q, 0u, (int32_t)k, 0, 0, plev[d], 0};
-                if (row < block_end_col) {          // a later panel of the same block: this panel's columns
-                    p.t_begin = (int32_t)(c0[d] - sc);
-                    p.t_end = (int32_t)(c0[d + 1] - sc);
-                } else if (row < se) {              // the rest of the supernode: the whole block, once it is complete
-                    if (!last_in_block) break;
-                    p.t_begin = (int32_t)(c0[blk0] - sc);
-                    p.t_end = (int32_t)(c0[blk1] - sc);
-                } else {                            // ancestors: the whole supernode, once it is complete
-                    if (!last) break;
-                    p.t_begin = 0;
-                    p.t_end = (int32_t)(se - sc);
-                    p.atomic = 1;
+    // (supernodes are independent here: contiguous ranges of them on the host threads, cut by the entries of L they hold, each
+    // range into a list of its own; the lists are joined in order, so the pairs come out as one thread would produce them)
+    const auto pairs_of = [&](i64 k0, i64 k1, std::vector<Pair> &out) {
+        for (i64 k = k0; k < k1; ++k) {
+            const i64 sc = super[k], se = super[k + 1];
+            for (i64 d = first_panel[k]; d < first_panel[k + 1]; ++d) {
+                if (tiny[d] && !grouped) continue;  // the tiny kernel applies its own updates, except in target-owned mode
+                const i64 *Rd = R(d);
+                const i64 rd = prow[d];
+                const i64 blk0 = first_panel[k] + (d - first_panel[k]) / bp * bp;      // first panel of d's block
+                const i64 blk1 = std::min<i64>(blk0 + bp, first_panel[k + 1]);          // one past its last panel
+                const bool last_in_block = d + 1 == blk1, last = d + 1 == first_panel[k + 1];
+                const i64 block_end_col = c0[blk1];  // == se for the last block
+                for (i64 q = 0; q < rd;) {
+                    const i64 row = Rd[q];
+                    Pair p{(int32_t)d, panel_of[row], (int32_t)q, 0u, (int32_t)k, 0, 0, plev[d], 0};
+                    if (row < block_end_col) {          // a later panel of the same block: this panel's columns
+                        p.t_begin = (int32_t)(c0[d] - sc);
+                        p.t_end = (int32_t)(c0[d + 1] - sc);
+                    } else if (row < se) {              // the rest of the supernode: the whole block, once it is complete
+                        if (!last_in_block) break;
+                        p.t_begin = (int32_t)(c0[blk0] - sc);
+                        p.t_end = (int32_t)(c0[blk1] - sc);
+                    } else {                            // ancestors: the whole supernode, once it is complete
+                        if (!last) break;
+                        p.t_begin = 0;
+                        p.t_end = (int32_t)(se - sc);
+                        p.atomic = 1;
+                    }
+                    for (; q < rd && Rd[q] < c0[p.s + 1]; ++q) p.mask |= 1u << (Rd[q] - c0[p.s]);
+                    out.push_back(p);
                 }
-                for (; q < rd && Rd[q] < c0[p.s + 1]; ++q) p.mask |= 1u << (Rd[q] - c0[p.s]);
-                pairs.push_back(p);
             }
         }
+    };
+    {
+        const i64 threads = std::max<i64>(1, std::min<i64>(host_threads(), nsuper_ >> 14));
+        std::vector<i64> cut((size_t)threads + 1, nsuper_);
+        cut[0] = 0;
+        for (i64 t = 1; t < threads; ++t) {  // first supernode whose first entry of L lies at or beyond the t-th share
+            const i64 want = lnz_ * t / threads;
+            cut[(size_t)t] = std::lower_bound(super.begin(), super.end() - 1, want, [&](i64 col, i64 w) { return Lp_[col] < w; }) - super.begin();
+        }
+        std::vector<std::vector<Pair>> part((size_t)threads);
+        std::vector<std::thread> pool;
+        for (i64 t = 1; t < threads; ++t) pool.emplace_back(pairs_of, cut[(size_t)t], cut[(size_t)t + 1], std::ref(part[(size_t)t]));
+        pairs_of(cut[0], cut[1], part[0]);
+        for (std::thread &th : pool) th.join();
+        size_t total = 0;
+        for (const auto &v : part) total += v.size();
+        pairs.reserve(total);
+        for (const auto &v : part) pairs.insert(pairs.end(), v.begin(), v.end());
     }
     lap("panels, levels, pairs");
     std::vector<dev::CholTiny> tiny_items;
@@ -396,17 +418,54 @@ int CholFactor::analyze(const CscView &A, const Symbolic &S, bool single_use)
             }
         });
         lap("  tiles: records");
-        for (size_t x = 0; x < keys.size(); ++x) {
-            const Key &key = keys[x];
-            const Pair &p = pairs[key.pair];
-            const bool fresh = x == 0 || keys[x - 1].level != key.level || keys[x - 1].s != key.s || keys[x - 1].r16 != key.r16;
-            if (fresh) {
-                groups.push_back(dev::CholGroup{Lp_[c0[p.s]], (i64)x, (c0[p.s + 1] - c0[p.s]) + prow[p.s], c0[p.s + 1] - c0[p.s], key.r16, 0});
-                group_level.push_back(key.level);
-                group_long.push_back(0);
-            }
-            groups.back().sub_count++;
-            if (p.t_end - p.t_begin > 4) group_long.back() = 1;
+        // groups: a new one wherever (level, panel, tile) changes -- marked and counted on the host threads, then filled
+        const i64 nkeys = (i64)keys.size();
+        const auto fresh_at = [&](i64 x) {
+            return x == 0 || keys[x - 1].level != keys[x].level || keys[x - 1].s != keys[x].s || keys[x - 1].r16 != keys[x].r16;
+        };
+        const i64 gthreads = std::max<i64>(1, std::min<i64>(host_threads(), nkeys >> 16));
+        std::vector<i64> gcut((size_t)gthreads + 1), gfirst((size_t)gthreads + 1, 0);
+        for (i64 t = 0; t <= gthreads; ++t) gcut[(size_t)t] = nkeys * t / gthreads;
+        {
+            std::vector<std::thread> pool;
+            const auto count = [&](i64 t) {
+                i64 c = 0;
+                for (i64 x = gcut[(size_t)t]; x < gcut[(size_t)t + 1]; ++x) c += fresh_at(x);
+                gfirst[(size_t)t + 1] = c;
+            };
+            for (i64 t = 1; t < gthreads; ++t) pool.emplace_back(count, t);
+            count(0);
+            for (std::thread &th : pool) th.join();
+        }
+        for (i64 t = 0; t < gthreads; ++t) gfirst[(size_t)t + 1] += gfirst[(size_t)t];
+        groups.resize((size_t)gfirst[(size_t)gthreads]);
+        group_level.resize(groups.size());
+        group_long.assign(groups.size(), 0);
+        {
+            std::vector<std::thread> pool;
+            // a thread owns the groups that START in its range and follows the last of them into the next range
+            const auto fill = [&](i64 t) {
+                i64 g = gfirst[(size_t)t] - 1;
+                i64 x = gcut[(size_t)t];
+                while (x < gcut[(size_t)t + 1] && !fresh_at(x)) ++x;  // (the tail of a group that started earlier: its owner's)
+                if (x >= gcut[(size_t)t + 1]) return;                 // no group starts in this range
+                for (; x < nkeys; ++x) {
+                    const bool fresh = fresh_at(x);
+                    if (fresh && x >= gcut[(size_t)t + 1]) break;
+                    const Key &key = keys[x];
+                    const Pair &p = pairs[key.pair];
+                    if (fresh) {
+                        ++g;
+                        groups[(size_t)g] = dev::CholGroup{Lp_[c0[p.s]], x, (c0[p.s + 1] - c0[p.s]) + prow[p.s], c0[p.s + 1] - c0[p.s], key.r16, 0};
+                        group_level[(size_t)g] = key.level;
+                    }
+                    groups[(size_t)g].sub_count++;
+                    if (p.t_end - p.t_begin > 4) group_long[(size_t)g] = 1;
+                }
+            };
+            for (i64 t = 1; t < gthreads; ++t) pool.emplace_back(fill, t);
+            fill(0);
+            for (std::thread &th : pool) th.join();
         }
     }
     lap("target tiles");
