@@ -1,6 +1,9 @@
 // Device-side objects of librsparse_hip: RAII buffers, the triangular-solve engine and the numeric
 // Cholesky engine.  Everything here runs on the GPU; there is no CPU fallback for numeric work.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -27,10 +30,39 @@ struct DeviceError : std::runtime_error {
 
 // An n x nrhs column-major block between host (leading dimension ld_host) and device (packed, leading dimension n): one
 // plain copy when the host block is packed too, else one per column.  Not hipMemcpy2D: under rocprofv3 (kernel trace or
-// counters) its host-to-device form delivered a wrong block on this ROCm (7.2.0; seen as a residual of 4.9 in a
-// one-column solve that is exact outside the profiler).
+// counters) its host-to-device form, inside this library's process, returns hipSuccess and copies NOTHING every other
+// call or so on this ROCm (7.2.0; first seen as a residual of 4.9 in a one-column solve that is exact outside the
+// profiler).  Established in round 3 with the diagnostic below (RSP_COPY_2D_CHECK=1, tools/r3_copy2d_incident.sh;
+// profiles/r03_memcpy2d_incident.txt): the block read back right after the call, and again after hipDeviceSynchronize,
+// is the buffer's old contents -- lost, not late; a standalone single-threaded program does not show it.
 inline void copy_block_to_device(double *d, const double *h, i64 n, i64 ld_host, i64 nrhs)
 {
+    if (const char *dbg = std::getenv("RSP_COPY_2D_CHECK")) {  // diagnostic: the hipMemcpy2D form, read back and compared
+        if (dbg[0] == '1') {
+            RSP_HIP(hipMemcpy2D(d, (size_t)n * sizeof(double), h, (size_t)ld_host * sizeof(double), (size_t)n * sizeof(double), (size_t)nrhs,
+                                hipMemcpyHostToDevice));
+            std::vector<double> back((size_t)n * (size_t)nrhs);
+            RSP_HIP(hipMemcpy(back.data(), d, back.size() * sizeof(double), hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (i64 j = 0; j < nrhs; ++j)
+                for (i64 i = 0; i < n; ++i) bad += back[(size_t)(j * n + i)] != h[(size_t)(j * ld_host + i)];
+            std::fprintf(stderr, "copy check: hipMemcpy2D of %lld x %lld (ld %lld): %zu entries differ right after the copy\n", (long long)n,
+                         (long long)nrhs, (long long)ld_host, bad);
+            if (bad) {  // late or lost?  once more after the whole device has drained
+                RSP_HIP(hipDeviceSynchronize());
+                RSP_HIP(hipMemcpy(back.data(), d, back.size() * sizeof(double), hipMemcpyDeviceToHost));
+                size_t still = 0, zeros = 0;
+                for (i64 j = 0; j < nrhs; ++j)
+                    for (i64 i = 0; i < n; ++i) {
+                        still += back[(size_t)(j * n + i)] != h[(size_t)(j * ld_host + i)];
+                        zeros += back[(size_t)(j * n + i)] == 0.0;
+                    }
+                std::fprintf(stderr, "copy check:   after hipDeviceSynchronize: %zu entries differ (%zu of the block's entries are 0.0); repaired with a plain copy\n",
+                             still, zeros);
+            }
+            if (!bad) return;  // (else: the plain copies below)
+        }
+    }
     if (nrhs == 1 || ld_host == n) {
         RSP_HIP(hipMemcpy(d, h, (size_t)n * (size_t)nrhs * sizeof(double), hipMemcpyHostToDevice));
         return;
