@@ -101,8 +101,24 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)  // src_l
     return __hiloint2double(hi, lo);
 }
 
+// COH (solve_levels_flagged: several levels in one launch): rows of X and scratch rows written by another wavefront of the SAME
+// launch are read past the caches that are not coherent across XCDs (agent-scope accesses).  Plain loads would not be safe
+// even though every row is written once: narrow blocks put 16 rows into one cache line, and an XCD that fetched the line
+// for a finished neighbour would serve a stale copy of a row that was still pending.
+template <bool COH>
+__device__ __forceinline__ double load_x(const double *p)
+{
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH>
+__device__ __forceinline__ void store_x(double *p, double v)
+{
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // ---- vector path: RC <= 4 unknowns, one right-hand side per lane ---------------------------------------
-template <int RC>
+template <int RC, bool COH = false>
 __device__ __forceinline__ void run_block_vec(const BlockHeader h, const Prologue &R, const BlockArrays &B, double *X, int64_t ldx, double *S,
                                               int64_t lds, int col, bool live, int lane)
 {
@@ -119,7 +135,7 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const Prologu
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
         const int32_t id = __builtin_amdgcn_readlane(R.r0, 24 + r);
-        acc[r] = (id != RSP_NONE && live) ? row_ptr(id, X, ldx, S, lds)[col] : 0.0;
+        acc[r] = (id != RSP_NONE && live) ? load_x<COH>(row_ptr(id, X, ldx, S, lds) + col) : 0.0;
     }
     for (int e0 = 0; e0 < h.nsrc; e0 += SB) {
         double x[SB];
@@ -127,7 +143,7 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const Prologu
         for (int u = 0; u < SB; ++u) {
             if (u < nb) {  // wave-uniform
                 const int32_t id = __builtin_amdgcn_readlane(idv, u);
-                x[u] = live ? row_ptr(id, X, ldx, S, lds)[col] : 0.0;
+                x[u] = live ? load_x<COH>(row_ptr(id, X, ldx, S, lds) + col) : 0.0;
             } else {
                 x[u] = 0.0;
             }
@@ -158,7 +174,7 @@ __device__ __forceinline__ void run_block_vec(const BlockHeader h, const Prologu
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
         const int32_t id = __builtin_amdgcn_readlane(R.r0, 8 + r);
-        if (id != RSP_NONE && live) const_cast<double *>(row_ptr(id, X, ldx, S, lds))[col] = acc[r];
+        if (id != RSP_NONE && live) store_x<COH>(const_cast<double *>(row_ptr(id, X, ldx, S, lds)) + col, acc[r]);
     }
 }
 
@@ -211,7 +227,7 @@ struct PanelCtx {
 };
 
 // this lane's piece of row `id`: FAST layout (aligned, whole pieces) with one 64-bit multiply-add per address
-template <bool FAST, int NT>
+template <bool FAST, int NT, bool COH = false>
 __device__ __forceinline__ Piece<NT> load_piece(int32_t id, const PanelCtx &c)
 {
     Piece<NT> r;
@@ -226,19 +242,19 @@ __device__ __forceinline__ Piece<NT> load_piece(int32_t id, const PanelCtx &c)
             const f64x2 lo = *reinterpret_cast<const f64x2 *>(p);
             r.v[0] = lo.x; r.v[1] = lo.y;
         } else {
-            r.v[0] = *reinterpret_cast<const double *>(p);
+            r.v[0] = load_x<COH>(reinterpret_cast<const double *>(p));
         }
     } else {
         const double *p = row_ptr(id, c.X, c.ldx, c.S, c.lds) + c.cb;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) r.v[nt] = c.cb + nt < c.nrhs ? p[nt] : 0.0;
+        for (int nt = 0; nt < NT; ++nt) r.v[nt] = c.cb + nt < c.nrhs ? load_x<COH>(p + nt) : 0.0;
     }
     return r;
 }
 
 // K-steps [slot * Q, ...) of the current WINDOW, whose ids the record registers (ids0, ids1) hold (16 K-steps per
 // register); `slot` and `nslots` count inside the window.  Slots past the end read row 0 of X (never used).
-template <bool FAST, int Q, int NT>
+template <bool FAST, int Q, int NT, bool COH = false>
 __device__ __forceinline__ void load_slot(Slot<Q, NT> &R, int32_t ids0, int32_t ids1, const PanelCtx &c, const double *cfw, int slot, int nslots)
 {
     const bool valid = slot < nslots;  // wave-uniform
@@ -248,7 +264,7 @@ __device__ __forceinline__ void load_slot(Slot<Q, NT> &R, int32_t ids0, int32_t 
         int32_t id = __builtin_amdgcn_ds_bpermute(((4 * k + c.g) & 63) << 2, (k & 16) ? ids1 : ids0);
         id = valid ? id : 0;
         R.a[q] = cfw[(valid ? (int64_t)k * 64 : 0) + c.lane];
-        R.b[q] = load_piece<FAST, NT>(id, c);
+        R.b[q] = load_piece<FAST, NT, COH>(id, c);
     }
 }
 
@@ -276,7 +292,7 @@ __device__ __forceinline__ void load_panel_tinv(PanelIds &P, const BlockHeader h
 
 // initial rows of the block -> v (register s <- unknown 4s + g); the loads are unconditional (rows that do not exist
 // read row 0 and are zeroed afterwards), so all of them travel together with the ring's first slots
-template <bool FAST, int NT>
+template <bool FAST, int NT, bool COH = false>
 __device__ __forceinline__ void panel_load_init(f64x4 (&v)[NT], const Prologue &R, const PanelCtx &c, bool lead)
 {
     int32_t id[4];
@@ -287,7 +303,7 @@ __device__ __forceinline__ void panel_load_init(f64x4 (&v)[NT], const Prologue &
     }
     Piece<NT> piece[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) piece[s] = load_piece<FAST, NT>(id[s] != RSP_NONE ? id[s] : 0, c);
+    for (int s = 0; s < 4; ++s) piece[s] = load_piece<FAST, NT, COH>(id[s] != RSP_NONE ? id[s] : 0, c);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const bool have = id[s] != RSP_NONE && (!FAST || c.in);
@@ -302,7 +318,7 @@ __device__ __forceinline__ void panel_load_init(f64x4 (&v)[NT], const Prologue &
 // triangle fetched at the end).  NL: id lines of the record.  One right-hand side takes the same path (16-column
 // wavefronts, element-wise loads): a special all-stages-at-once gather that fetched its ids from the pool cost one more
 // dependent round trip per block than the record's id lines (2.53 against 2.39 ms per cholsol solve phase at C2).
-template <bool FAST, bool LAT, int NL, int NT>
+template <bool FAST, bool LAT, int NL, int NT, bool COH = false>
 __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, const Prologue &R, const BlockHeader h, const PanelCtx &c,
                                              int st_begin, int st_end, bool lead)
 {
@@ -318,7 +334,7 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, cons
     // (the sched_barriers pin the ORDER in which loads are issued: loads return in order, and the compiler's scheduler
     // would otherwise happily issue the slot that is needed first last)
     if (LAT) {
-        panel_load_init<FAST, NT>(acc, R, c, lead);
+        panel_load_init<FAST, NT, COH>(acc, R, c, lead);
         load_panel_tinv(P, h, c);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -328,7 +344,7 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, cons
         const int nslots = min(nks, WIN) / Q;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            load_slot<FAST, Q, NT>(ring[d], ids0, ids1, c, cfw, d, nslots);
+            load_slot<FAST, Q, NT, COH>(ring[d], ids0, ids1, c, cfw, d, nslots);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -340,7 +356,7 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, cons
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 if (base + d < nslots) mfma_slot<Q, NT>(acc, ring[d]);  // wave-uniform
-                load_slot<FAST, Q, NT>(ring[d], ids0, ids1, c, cfw, base + d + D, nslots);
+                load_slot<FAST, Q, NT, COH>(ring[d], ids0, ids1, c, cfw, base + d + D, nslots);
                 __builtin_amdgcn_sched_barrier(0);  // keep the re-fill where it is: right behind the slot's last use
             }
         }
@@ -356,13 +372,13 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, cons
         const int nnext = min(nks - w0, WIN) / Q;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            load_slot<FAST, Q, NT>(ring[d], ids0, ids1, c, cfw, d, nnext);
+            load_slot<FAST, Q, NT, COH>(ring[d], ids0, ids1, c, cfw, d, nnext);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (!LAT && lead) {  // wave-uniform
         f64x4 init[NT];
-        panel_load_init<FAST, NT>(init, R, c, true);
+        panel_load_init<FAST, NT, COH>(init, R, c, true);
         load_panel_tinv(P, h, c);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] -= init[nt];
@@ -370,7 +386,7 @@ __device__ __forceinline__ void panel_gather(f64x4 (&acc)[NT], PanelIds &P, cons
 }
 
 // acc -> -acc, in-block triangle (as its inverse) and the store of the 16 unknowns
-template <bool FAST, int NT>
+template <bool FAST, int NT, bool COH = false>
 __device__ __forceinline__ void panel_finish(f64x4 (&acc)[NT], const PanelIds &P, const BlockHeader h, const PanelCtx &c, double *X, double *S)
 {
 #pragma unroll
@@ -397,13 +413,13 @@ __device__ __forceinline__ void panel_finish(f64x4 (&acc)[NT], const PanelIds &P
                     } else if constexpr (NT == 2) {
                         *reinterpret_cast<f64x2 *>(p) = f64x2{acc[0][s], acc[1][s]};
                     } else {
-                        p[0] = acc[0][s];
+                        store_x<COH>(p, acc[0][s]);
                     }
                 }
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (c.cb + nt < c.nrhs) p[nt] = acc[nt][s];
+                    if (c.cb + nt < c.nrhs) store_x<COH>(p + nt, acc[nt][s]);
             }
         }
     }
@@ -432,15 +448,15 @@ __device__ __forceinline__ PanelCtx make_ctx(const BlockHeader h, const BlockArr
     return c;
 }
 
-template <bool FAST, bool LAT, int NT>
+template <bool FAST, bool LAT, int NT, bool COH = false>
 __device__ __forceinline__ void run_block_mfma(const BlockHeader h, const Prologue &R, const BlockArrays &B, double *X, int64_t ldx, double *S,
                                                int64_t lds, int cw, int nrhs, int lane)
 {
     const PanelCtx c = make_ctx<NT>(h, B, X, ldx, S, lds, cw, nrhs, lane);
     PanelIds P;
     f64x4 acc[NT];
-    panel_gather<FAST, LAT, 1, NT>(acc, P, R, h, c, 0, h.nsrc >> 4, true);
-    panel_finish<FAST, NT>(acc, P, h, c, X, S);
+    panel_gather<FAST, LAT, 1, NT, COH>(acc, P, R, h, c, 0, h.nsrc >> 4, true);
+    panel_finish<FAST, NT, COH>(acc, P, h, c, X, S);
 }
 
 // ---- one launch per level ----------------------------------------------------------------------------------------
@@ -465,7 +481,7 @@ struct LevelDesc {
 
 // class 0: the blocks of a task run in order.  t = task number inside the launch.  A wavefront owns 16 NT columns; the
 // vector path (one column per lane) then uses the first 16 NT lanes only.
-template <bool FAST, bool LAT, int NT>
+template <bool FAST, bool LAT, int NT, bool COH = false>
 __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task_begin, int t, int64_t blk0, int64_t rec0, bool single, int chunk,
                                          double *X, int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
@@ -481,10 +497,10 @@ __device__ __forceinline__ void run_task(const BlockArrays &B, int64_t task_begi
         const Prologue R = load_prologue<2, 1>(B, rec0 + 2 * (b - blk0), lane);
         const BlockHeader h = header_of(R);
         switch (h.rc) {
-            case 16: run_block_mfma<FAST, LAT, NT>(h, R, B, X, ldx, S, lds, cw, nrhs, lane); break;
-            case 1: run_block_vec<1>(h, R, B, X, ldx, S, lds, col, live, lane); break;
-            case 2: run_block_vec<2>(h, R, B, X, ldx, S, lds, col, live, lane); break;
-            default: run_block_vec<4>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            case 16: run_block_mfma<FAST, LAT, NT, COH>(h, R, B, X, ldx, S, lds, cw, nrhs, lane); break;
+            case 1: run_block_vec<1, COH>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            case 2: run_block_vec<2, COH>(h, R, B, X, ldx, S, lds, col, live, lane); break;
+            default: run_block_vec<4, COH>(h, R, B, X, ldx, S, lds, col, live, lane); break;
         }
     }
 }
@@ -501,7 +517,7 @@ __device__ __forceinline__ void split_item(int q, int n, int nchunks, int &blk, 
 
 // W wavefronts (w = 0..W-1) share one matrix-core block: contiguous ranges of its stages each, partial accumulators
 // meet in LDS (red: (W - 1) x 2 NT KiB), wavefront 0 finishes.  Every wavefront of the workgroup reaches the barrier.
-template <int W, bool FAST, bool LAT, int NT>
+template <int W, bool FAST, bool LAT, int NT, bool COH = false>
 __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int64_t rec, int chunk, int w, double *red, double *X,
                                           int64_t ldx, double *S, int64_t lds, int nrhs, int lane)
 {
@@ -517,7 +533,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
         if (W == 8) TCLK(1);
         c = make_ctx<NT>(h, B, X, ldx, S, lds, chunk * 16 * NT, nrhs, lane);
         const int nst = h.nsrc >> 4;
-        panel_gather<FAST, LAT, NL, NT>(acc, P, R, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
+        panel_gather<FAST, LAT, NL, NT, COH>(acc, P, R, h, c, (nst * w) / W, (nst * (w + 1)) / W, w == 0);
 #ifdef RSP_TRI_CLOCKS
         if (W == 8) {
             double sm = 0;
@@ -545,7 +561,7 @@ __device__ __forceinline__ void run_split(const BlockArrays &B, bool valid, int6
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc[nt][s] += theirs[(nt * 4 + s) * 64];
         }
-        panel_finish<FAST, NT>(acc, P, h, c, X, S);
+        panel_finish<FAST, NT, COH>(acc, P, h, c, X, S);
         if (W == 8) TCLK(4);
     }
 }
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(256) void solve_level_small(BlockArrays B, int64_t 
 }
 
 // One workgroup of a level: `item` is its (XCD-aware) number inside the level.  nchunks counts chunks of 16 NT columns.
-template <bool FAST, bool LAT, int NT>
+template <bool FAST, bool LAT, int NT, bool COH = false>
 __device__ __forceinline__ void level_workgroup(const BlockArrays &B, const LevelDesc &L, int item, int w, double *red, double *X, int64_t ldx,
                                                 double *S, int64_t lds, int nrhs, int nchunks, int lane)
 {
@@ -588,18 +604,18 @@ __device__ __forceinline__ void level_workgroup(const BlockArrays &B, const Leve
     if (item < L.wg2) {  // 1 (block, chunk) pair, 8 wavefronts
         int blk, chunk;
         split_item(item, L.nblk[1], nchunks, blk, chunk);
-        run_split<8, FAST, LAT, NT>(B, true, L.rec_begin[1] + (int64_t)blk * 24, chunk, w, red, X, ldx, S, lds, nrhs, lane);
+        run_split<8, FAST, LAT, NT, COH>(B, true, L.rec_begin[1] + (int64_t)blk * 24, chunk, w, red, X, ldx, S, lds, nrhs, lane);
     } else if (item < L.wg2 + L.wg1) {  // 2 (block, chunk) pairs, 4 wavefronts each
         const int q = (item - L.wg2) * 2 + (w >> 2);
         const bool valid = q < L.nblk[0] * nchunks;
         int blk = 0, chunk = 0;
         if (valid) split_item(q, L.nblk[0], nchunks, blk, chunk);
-        run_split<4, FAST, LAT, NT>(B, valid, L.rec_begin[0] + (int64_t)blk * 8, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 256 * NT, X, ldx, S, lds, nrhs,
+        run_split<4, FAST, LAT, NT, COH>(B, valid, L.rec_begin[0] + (int64_t)blk * 8, chunk, w & 3, red + (size_t)(w >> 2) * 3 * 256 * NT, X, ldx, S, lds, nrhs,
                                     lane);
     } else if (item < L.wg2 + L.wg1 + L.wg0) {  // 8 (task, chunk) pairs
         const int pair = (item - L.wg2 - L.wg1) * 8 + w;
         const int t = pair / nchunks;
-        if (t < L.ntasks) run_task<FAST, LAT, NT>(B, L.task_begin, t, L.blk0, L.rec0, L.single != 0, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
+        if (t < L.ntasks) run_task<FAST, LAT, NT, COH>(B, L.task_begin, t, L.blk0, L.rec0, L.single != 0, pair - t * nchunks, X, ldx, S, lds, nrhs, lane);
     }
 }
 
@@ -613,6 +629,75 @@ __global__ __launch_bounds__(512, LAT ? 2 : 4) void solve_level(BlockArrays B, L
     const int per_xcd = (int)(gridDim.x >> 3);                              // the grid is a multiple of 8 workgroups
     const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     level_workgroup<FAST, LAT, NT>(B, L, item, w, red, X, ldx, S, lds, nrhs, nchunks, lane);
+}
+
+// ---- several consecutive latency-bound levels in ONE launch (narrow blocks: at most 16 columns) --------------------------
+// A launch per level costs ~9 us when the level is a handful of workgroups whose own chain is ~4 us.  Here the workgroups of a
+// RUN of such levels are one grid.  A workgroup takes a TICKET from a counter (tickets are numbered level by level, so that
+// everything a ticket waits for was taken earlier, by a workgroup that is running), looks up its (level, item), waits for the
+// tickets that produce its sources -- a host-built list per ticket, only producers of the same run; a flag per ticket, the
+// whole first wavefront polling one flag at a time -- runs the level's ordinary code with coherent row accesses (COH) and
+// raises its own flag once its stores have landed.  Nobody counts arrivals and nothing is fenced: the hand-over is one
+// store and one poll, as in solve_rows_flagged.  Every wait is bounded (a flag that never rises is a defect: the wait gives
+// up and marks the run, every other wait sees the mark, the grid drains, the host reports RSP_DEVICE_ERROR).
+struct FlagRun {
+    const LevelDesc *levels;   // of the run
+    const int2 *tickets;       // (level of the run, item inside the level)
+    const int32_t *wait_ptr;   // producers of ticket k: wait_list[wait_ptr[k] .. wait_ptr[k + 1]) (flag indices)
+    const int32_t *wait_list;
+    int *flags;                // flags[flag_base + k] == epoch: ticket k is done
+    int *counter;              // next ticket (zero before the launch)
+    int *failed;
+    int flag_base, ntickets, epoch;
+    unsigned spin_limit;
+};
+
+template <bool FAST>
+__global__ __launch_bounds__(512, 2) void solve_levels_flagged(BlockArrays B, FlagRun F, double *X, int64_t ldx, double *S, int64_t lds, int nrhs)
+{
+    extern __shared__ double red[];  // 7 x 2 KiB
+    __shared__ int ticket;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x == 0) ticket = atomicAdd(F.counter, 1);
+    __syncthreads();
+    const int k = __builtin_amdgcn_readfirstlane(ticket);
+    if (k >= F.ntickets) return;  // (the whole workgroup)
+    const int2 where = F.tickets[k];
+    const LevelDesc L = F.levels[where.x];
+    if (w == 0) {
+        const int begin = F.wait_ptr[k], end = F.wait_ptr[k + 1];
+        unsigned spins = 0;
+        bool gave_up = false;
+        for (int p0 = begin; p0 < end && !gave_up; p0 += 64) {
+            const bool in = p0 + lane < end;
+            const int f = in ? F.wait_list[p0 + lane] : 0;
+            bool ready = !in || __hip_atomic_load(F.flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == F.epoch;
+            unsigned long long waiting = __ballot(!ready);
+            while (waiting) {  // (uniform) the whole wavefront polls the first missing producer
+                const int fw = __builtin_amdgcn_readlane(f, __builtin_ctzll(waiting));
+                while (__hip_atomic_load(F.flags + fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != F.epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0) {
+                        if (spins >= F.spin_limit && lane == 0) atomicExch(F.failed, 1);
+                        if (__hip_atomic_load(F.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            gave_up = true;
+                            break;
+                        }
+                    }
+                }
+                if (gave_up) break;
+                ready = !in || __hip_atomic_load(F.flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == F.epoch;
+                waiting = __ballot(!ready);
+            }
+        }
+    }
+    __syncthreads();
+    level_workgroup<FAST, true, 1, true>(B, L, where.y, w, red, X, ldx, S, lds, nrhs, 1, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wavefront's rows are in the L2 / on their way out before the flag is
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(F.flags + F.flag_base + k, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace dev

@@ -172,6 +172,19 @@ struct BlockedProgram {
         int nitems, item_ksteps_max;
     };
     std::vector<Level> levels;
+    // RSP_FLAGGED_LEVELS=1 (one right-hand side): runs of consecutive latency-bound levels that go out as ONE launch each
+    // (dev::solve_levels_flagged): per run its level descriptors and tickets, per ticket the flags it waits for
+    struct FlagRunHost {
+        size_t level_begin, level_end;  // levels [begin, end) of the programme
+        i64 level_off, ticket_off;      // into fr_levels (descriptors) and the per-ticket arrays
+        int nlevels, ntickets;
+    };
+    std::vector<FlagRunHost> flag_runs;
+    DeviceBuffer<char> fr_levels, fr_tickets;  // dev::LevelDesc, int2
+    DeviceBuffer<int32_t> fr_wait_ptr, fr_wait_list;
+    DeviceBuffer<int> fr_flags, fr_counters, fr_failed;
+    int fr_epoch = 0;
+    bool fr_ran = false;
     size_t device_bytes() const
     {
         return task_ptr.bytes() + hdr.bytes() + prologue.bytes() + src_idx.bytes() + coef.bytes() + clusters.bytes() + cluster_ids.bytes() +
@@ -296,6 +309,7 @@ class TriSolver {
         bool uploaded = false, pattern_only = false;
     } rows_;
     void upload_rows_schedule();
+    void build_flag_runs(const BlockProgram &P);  // (the host programme, before its arrays are moved to the device)
     void run_rows(double *x, hipStream_t stream);
     std::unique_ptr<BlockProgram> staged_;
     std::unique_ptr<BlockProgram> kept_;  // keep_for_refill(): coef, groups and the recipe of the resident programme

@@ -183,6 +183,170 @@ int analyze_pair(TriSolver &a, const CscView &Ta, int kind_a, TriSolver &b, cons
     return sa != kOk ? sa : sb;
 }
 
+// what the block kernel of one level runs for ONE column chunk, twin blocks of wide items included, no separate small-block
+// launch (the description run_window makes for a narrow block); returns the level's workgroups
+static int describe_narrow_level(const BlockedProgram::Level &lv, bool single_block_tasks, dev::LevelDesc &L)
+{
+    const int n01 = lv.ntasks[0] + lv.ntasks[1] + lv.ntasks[2];
+    L.task_begin = lv.task_begin[0];
+    L.block_begin[0] = lv.block_begin[3];
+    L.block_begin[1] = lv.block_begin[5];
+    L.blk0 = lv.block_begin[0];
+    L.rec0 = lv.rec_begin[0];
+    L.rec_begin[0] = lv.rec_begin[3];
+    L.rec_begin[1] = lv.rec_begin[5];
+    L.single = single_block_tasks ? 1 : 0;
+    L.ntasks = n01;
+    L.nblk[0] = lv.ntasks[3] + lv.ntasks[4];
+    L.nblk[1] = lv.ntasks[5] + lv.ntasks[6];
+    L.wg0 = (n01 + 7) / 8;
+    L.wg1 = (L.nblk[0] + 1) / 2;
+    L.wg2 = L.nblk[1];
+    return L.wg0 + L.wg1 + L.wg2;
+}
+
+void TriSolver::build_flag_runs(const BlockProgram &P)
+{
+    BlockedProgram &D = blocked_;
+    D.flag_runs.clear();
+    const char *on = getenv("RSP_FLAGGED_LEVELS");
+    if (!on || on[0] != '1' || !D.single_block_tasks || n_ >= INT32_MAX) return;
+    const i64 lean_single = env_or("RSP_LEAN_WGS_SINGLE", kLeanLaunchWorkgroupsSingle);
+    const i64 small_waves = env_or("RSP_SMALL_WAVES", kSmallLaunchWaves);
+    // 0: nothing to launch (transparent inside a run), 1: a latency-bound block launch and nothing else, 2: anything else
+    const auto kind_of = [&](const BlockedProgram::Level &lv) {
+        dev::LevelDesc L;
+        const int wgs = describe_narrow_level(lv, true, L);
+        if (lv.nclusters == 0 && wgs == 0) return 0;
+        if (lv.nclusters || (lv.ntasks[0] > 0 && lv.ntasks[0] >= small_waves)) return 2;
+        return (wgs + 7) / 8 * 8 < lean_single ? 1 : 2;
+    };
+    std::vector<dev::LevelDesc> descs;
+    std::vector<int2> tickets;
+    std::vector<int32_t> wait_ptr(1, 0), wait_list;
+    std::vector<int32_t> owner_x((size_t)n_, -1), owner_s((size_t)std::max<i64>(1, P.scratch_rows), -1);
+    const auto owner_of = [&](int32_t id) -> int32_t & { return id >= 0 ? owner_x[(size_t)id] : owner_s[(size_t)(~id)]; };
+    // the blocks of ticket (L, item): one, two or up to eight
+    const auto blocks_of = [&](const dev::LevelDesc &L, int item, i64 (&b)[8]) {
+        int nb = 0;
+        if (item < L.wg2) {
+            b[nb++] = L.block_begin[1] + item;
+        } else if (item < L.wg2 + L.wg1) {
+            for (int h = 0; h < 2; ++h) {
+                const int q = (item - L.wg2) * 2 + h;
+                if (q < L.nblk[0]) b[nb++] = L.block_begin[0] + q;
+            }
+        } else {
+            for (int w = 0; w < 8; ++w) {
+                const int t = (item - L.wg2 - L.wg1) * 8 + w;
+                if (t < L.ntasks) b[nb++] = L.blk0 + t;
+            }
+        }
+        return nb;
+    };
+    std::vector<int32_t> stamp;
+    for (size_t l0 = 0; l0 < D.levels.size();) {
+        if (kind_of(D.levels[l0]) != 1) {
+            ++l0;
+            continue;
+        }
+        size_t l1 = l0, last = l0;
+        int members = 0;
+        for (; l1 < D.levels.size(); ++l1) {
+            const int kd = kind_of(D.levels[l1]);
+            if (kd == 2) break;
+            if (kd == 1) ++members, last = l1;
+        }
+        l1 = last + 1;
+        if (members < 2) {
+            l0 = l1;
+            continue;
+        }
+        BlockedProgram::FlagRunHost run;
+        run.level_begin = l0;
+        run.level_end = l1;
+        run.level_off = (i64)descs.size();
+        run.ticket_off = (i64)tickets.size();
+        run.nlevels = 0;
+        for (size_t l = l0; l < l1; ++l) {
+            dev::LevelDesc L;
+            const int wgs = describe_narrow_level(D.levels[l], true, L);
+            if (wgs == 0) continue;
+            for (int item = 0; item < wgs; ++item) tickets.push_back(int2{run.nlevels, item});
+            descs.push_back(L);
+            run.nlevels++;
+        }
+        run.ntickets = (int)((i64)tickets.size() - run.ticket_off);
+        // producers: who writes each row inside this run, then, per ticket, the earlier tickets whose rows it reads
+        for (int k = 0; k < run.ntickets; ++k) {
+            const int2 tk = tickets[(size_t)(run.ticket_off + k)];
+            i64 b[8];
+            const int nb = blocks_of(descs[(size_t)(run.level_off + tk.x)], tk.y, b);
+            for (int q = 0; q < nb; ++q) {
+                const BlockHeader &h = P.hdr[(size_t)b[q]];
+                for (int r = 0; r < h.rc; ++r) {
+                    const int32_t id = P.src_idx[(size_t)(h.src_off + r)];
+                    if (id != BlockProgram::kNone) owner_of(id) = k;
+                }
+            }
+        }
+        stamp.assign((size_t)run.ntickets, -1);
+        for (int k = 0; k < run.ntickets; ++k) {
+            const int2 tk = tickets[(size_t)(run.ticket_off + k)];
+            i64 b[8];
+            const int nb = blocks_of(descs[(size_t)(run.level_off + tk.x)], tk.y, b);
+            for (int q = 0; q < nb; ++q) {
+                const BlockHeader &h = P.hdr[(size_t)b[q]];
+                for (i64 e = h.rc; e < 2 * (i64)h.rc + h.nsrc; ++e) {  // initial-value rows and sources
+                    const int32_t id = P.src_idx[(size_t)(h.src_off + e)];
+                    if (id == BlockProgram::kNone) continue;
+                    const int32_t o = owner_of(id);
+                    // (o >= k: the row is written later in the run or by this ticket -- a padding entry with a zero
+                    // coefficient, or the ticket's own initial value)
+                    if (o < 0 || o >= k || stamp[(size_t)o] == k) continue;
+                    stamp[(size_t)o] = k;
+                    wait_list.push_back((int32_t)(run.ticket_off + o));
+                }
+            }
+            wait_ptr.push_back((int32_t)wait_list.size());
+        }
+        for (int k = 0; k < run.ntickets; ++k) {  // clear the owners for the next run
+            const int2 tk = tickets[(size_t)(run.ticket_off + k)];
+            i64 b[8];
+            const int nb = blocks_of(descs[(size_t)(run.level_off + tk.x)], tk.y, b);
+            for (int q = 0; q < nb; ++q) {
+                const BlockHeader &h = P.hdr[(size_t)b[q]];
+                for (int r = 0; r < h.rc; ++r) {
+                    const int32_t id = P.src_idx[(size_t)(h.src_off + r)];
+                    if (id != BlockProgram::kNone) owner_of(id) = -1;
+                }
+            }
+        }
+        D.flag_runs.push_back(run);
+        l0 = l1;
+    }
+    if (D.flag_runs.empty()) return;
+    D.fr_levels.resize(descs.size() * sizeof(dev::LevelDesc));
+    RSP_HIP(hipMemcpy(D.fr_levels.get(), descs.data(), descs.size() * sizeof(dev::LevelDesc), hipMemcpyHostToDevice));
+    D.fr_tickets.resize(tickets.size() * sizeof(int2));
+    RSP_HIP(hipMemcpy(D.fr_tickets.get(), tickets.data(), tickets.size() * sizeof(int2), hipMemcpyHostToDevice));
+    D.fr_wait_ptr.upload(wait_ptr);
+    wait_list.push_back(0);  // (never empty)
+    D.fr_wait_list.upload(wait_list);
+    D.fr_flags.resize(tickets.size());
+    RSP_HIP(hipMemset(D.fr_flags.get(), 0, tickets.size() * sizeof(int)));
+    D.fr_counters.resize(D.flag_runs.size());
+    D.fr_failed.resize(1);
+    RSP_HIP(hipMemset(D.fr_failed.get(), 0, sizeof(int)));
+    D.fr_epoch = 0;
+    if (getenv("RSP_TIMING")) {
+        i64 lv = 0;
+        for (const auto &r : D.flag_runs) lv += r.nlevels;
+        fprintf(stderr, "flagged levels: %zu runs holding %lld levels, %zu tickets, %zu waits\n", D.flag_runs.size(), (long long)lv, tickets.size(),
+                wait_list.size() - 1);
+    }
+}
+
 void TriSolver::build_blocked()
 {
     const double tb0 = now_s();
@@ -242,6 +406,8 @@ void TriSolver::build_blocked()
                     (long long)vec, D.levels[l].nclusters, D.levels[l].nitems, D.levels[l].item_ksteps_max);
         }
     }
+    D.single_block_tasks = D.ntasks == D.nblocks;
+    build_flag_runs(P);
     D.task_ptr.upload(P.task_ptr);
     D.hdr.upload(P.hdr);
     D.prologue.upload(P.prologue);
@@ -577,8 +743,36 @@ void TriSolver::run_window(double *X, i64 ld, i64 nrhs, i64 col_off, i64 total_c
     const bool narrow_block = nrhs <= 16;
     const i64 lean_threshold = nrhs == 1 ? lean_wgs_single : lean_wgs;
 
+    // one right-hand side, RSP_FLAGGED_LEVELS=1: runs of latency-bound levels as one launch each (build_flag_runs)
+    const bool flagged = nrhs == 1 && !scratch_override && !P.flag_runs.empty();
+    size_t next_run = 0;
+    if (flagged) {
+        ++blocked_.fr_epoch;
+        blocked_.fr_ran = true;
+        RSP_HIP(hipMemsetAsync(P.fr_counters.get(), 0, P.flag_runs.size() * sizeof(int), stream));
+    }
     bool recorded = false;
     for (size_t li = 0; li < P.levels.size(); ++li) {
+        if (flagged && next_run < P.flag_runs.size() && li == P.flag_runs[next_run].level_begin) {
+            const auto &run = P.flag_runs[next_run];
+            dev::FlagRun F;
+            F.levels = reinterpret_cast<const dev::LevelDesc *>(P.fr_levels.get()) + run.level_off;
+            F.tickets = reinterpret_cast<const int2 *>(P.fr_tickets.get()) + run.ticket_off;
+            F.wait_ptr = P.fr_wait_ptr.get() + run.ticket_off;
+            F.wait_list = P.fr_wait_list.get();
+            F.flags = P.fr_flags.get();
+            F.counter = P.fr_counters.get() + next_run;
+            F.failed = P.fr_failed.get();
+            F.flag_base = (int)run.ticket_off;
+            F.ntickets = run.ntickets;
+            F.epoch = P.fr_epoch;
+            F.spin_limit = (unsigned)env_or("RSP_FLAGGED_SPIN_LIMIT", 1 << 22);
+            if (fast) hipLaunchKernelGGL(dev::solve_levels_flagged<true>, dim3((unsigned)run.ntickets), dim3(512), 7 * 2048, stream, A, F, X, ld, Sw, lds, (int)nrhs);
+            else hipLaunchKernelGGL(dev::solve_levels_flagged<false>, dim3((unsigned)run.ntickets), dim3(512), 7 * 2048, stream, A, F, X, ld, Sw, lds, (int)nrhs);
+            li = run.level_end - 1;
+            ++next_run;
+            continue;
+        }
         const auto &lv = P.levels[li];
         if (after_heavy && !recorded && done * 10 >= total * 9) {
             RSP_HIP(hipEventRecord(after_heavy, stream));
@@ -846,6 +1040,15 @@ void TriSolver::run_rows(double *x, hipStream_t stream)
 
 void TriSolver::check_rows_run()
 {
+    if (blocked_.fr_ran) {  // RSP_FLAGGED_LEVELS=1: a wait inside a flagged launch gave up (a defect)
+        blocked_.fr_ran = false;
+        int failed = 0;
+        RSP_HIP(hipMemcpy(&failed, blocked_.fr_failed.get(), sizeof failed, hipMemcpyDeviceToHost));
+        if (failed) {
+            RSP_HIP(hipMemset(blocked_.fr_failed.get(), 0, sizeof(int)));
+            throw DeviceError("solve_levels_flagged: a workgroup gave up waiting for its producers");
+        }
+    }
     if (!rows_ran_) return;
     rows_ran_ = false;
     dev::RowsControl c{};
